@@ -1,0 +1,157 @@
+/* synth_mi355x.h -- C-ABI of libsynth_mi355x.so, the MI355X (gfx950) drop-in
+ * for the per-sample voice loops of zwizwa/synth_tools.
+ *
+ * Plain C: pointers and sizes only, no HIP/torch/C++ types.  Host glue (the
+ * JACK client, the Erlang port program, firmware-shaped control code) stays C
+ * and calls HIP through this boundary.  Every entry point cites the reference
+ * interface (file:line under /root/reference) that it replaces or widens.
+ *
+ * Conventions
+ *  - "bank" objects are opaque handles; voice/channel state is resident in
+ *    HBM, struct-of-arrays, one lane per voice.
+ *  - The four Linux names (synth_init/note_on/note_off/run) are exported
+ *    unchanged, with the reference's prototypes and its caller-owned
+ *    `struct synth` (linux/synth.c:31-45).  They are void, like the
+ *    reference; a HIP failure aborts the process with a message, which is the
+ *    reference's ASSERT convention (linux/erl_tools_system.h:15,24-27).
+ *  - All other calls return 0 on success and a negative code on error, the
+ *    firmware handlers' convention (mod_synth.c:91,106-107,113);
+ *    smx_last_error() gives the text.  There is NO CPU fallback: with no
+ *    usable GPU every compute call fails with SMX_E_NOGPU.
+ *  - Integer results are bit-exact with the reference CPU loops.
+ */
+#ifndef SYNTH_MI355X_H
+#define SYNTH_MI355X_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMX_OK          0
+#define SMX_E_ARG     (-1)   /* bad argument (mod_synth.c:91)            */
+#define SMX_E_RANGE   (-2)   /* index out of range (mod_synth.c:107)     */
+#define SMX_E_STATE   (-3)   /* wrong state / too many args (:113)       */
+#define SMX_E_NOGPU   (-10)  /* no HIP device / HIP runtime error        */
+#define SMX_E_COMM    (-11)  /* RCCL error                               */
+
+const char *smx_last_error(void);
+int  smx_device_count(void);             /* 0 when no GPU is visible      */
+int  smx_version(void);
+
+/* ======================================================================== */
+/* 1. Linux drop-in: linux/synth.c:31-45, 145-208                           */
+/* ======================================================================== */
+typedef uint32_t phasor_t;               /* linux/synth.c:29 */
+struct voice {                           /* linux/synth.c:31-34 */
+    phasor_t note_inc;                   /* 0 == off */
+    phasor_t note_state;
+};
+struct synth {                           /* linux/synth.c:35-38 */
+    int note2voice[128];
+    struct voice voice[64];
+};
+/* Same names, prototypes and observable behaviour as linux/synth.c:42-45.
+ * The caller owns *x (host memory); note_on/note_off only touch *x (as the
+ * reference does); synth_run mirrors voice[] to the GPU, runs the bank kernel
+ * for n frames, and writes vec[0..n) and the advanced note_state back. */
+void synth_note_on (struct synth *x, int note);      /* linux/synth.c:156-160 */
+void synth_note_off(struct synth *x, int note);      /* linux/synth.c:161-165 */
+void synth_init    (struct synth *x);                /* linux/synth.c:204-206 */
+void synth_run     (struct synth *x, float *vec, int n); /* linux/synth.c:196-202 */
+/* linux/synth.c:118-125 and :145-154, also global symbols in the reference. */
+phasor_t note_to_inc(int note);
+int      voice_alloc(struct synth *x);
+extern const uint8_t midi_tab[128];                  /* linux/synth.c:106-115 */
+/* MIDI dispatch of process_midi, linux/synth.c:236-258, for one event. */
+void synth_midi_event(struct synth *x, const uint8_t *msg, size_t size);
+
+/* ======================================================================== */
+/* 2. Saw voice bank: linux/synth.c widened from 64 to N voices             */
+/* ======================================================================== */
+typedef struct smx_bank smx_bank;
+
+/* n_voices >= 1.  device = HIP ordinal.  State zeroed (linux/synth.c:205). */
+smx_bank *smx_bank_create(uint32_t n_voices, int device);
+void      smx_bank_destroy(smx_bank *b);
+uint32_t  smx_bank_voices(const smx_bank *b);
+
+/* Bulk load / read back of inc[] and state[] (host arrays of n_voices).
+ * Either pointer may be NULL to skip that array. */
+int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *state);
+int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state);
+
+/* note_on/off over N voices with the reference's allocator semantics:
+ * first free voice, steal voice 0 when full, phase not reset, note_off of a
+ * never-played note silences voice 0 (linux/synth.c:145-165). */
+int smx_bank_note_on (smx_bank *b, int note);
+int smx_bank_note_off(smx_bank *b, int note);
+
+/* synth_run over the bank (linux/synth.c:196-202).  vec: host float[n] or
+ * NULL; bus: host int32[n] or NULL (the integer sum before the 2^-32 scale,
+ * linux/synth.c:170-179).  Synchronous. */
+int smx_bank_run(smx_bank *b, float *vec, int32_t *bus, int n);
+
+/* Asynchronous form: enqueue one block of n frames on the bank's stream and
+ * leave the int32 bus in device memory (smx_bank_bus_dev).  No host sync. */
+int   smx_bank_run_async(smx_bank *b, int n);
+void *smx_bank_bus_dev(smx_bank *b);     /* device int32[n] of the last block */
+int   smx_bank_sync(smx_bank *b);
+/* sum_tick_square (linux/synth.c:182-195) for n frames; vec host float[n]. */
+int smx_bank_run_square(smx_bank *b, float *vec, int n);
+
+/* Timing on the bank's own stream (HIP events; ms). */
+int smx_bank_timer_start(smx_bank *b);
+int smx_bank_timer_stop(smx_bank *b, float *ms);
+/* Kernel-only time of the last smx_bank_run_async calls since timer_start is
+ * the same interval when nothing else is enqueued on the stream. */
+
+/* ---- multi-GPU: per-GPU mix, then one int32 sum over xGMI (RCCL) -------- */
+#define SMX_UNIQUE_ID_BYTES 128
+int smx_comm_unique_id(uint8_t id[SMX_UNIQUE_ID_BYTES]);   /* rank 0 */
+int smx_bank_comm_init(smx_bank *b, int rank, int nranks,
+                       const uint8_t id[SMX_UNIQUE_ID_BYTES]);
+/* All-reduce (sum, int32) of the last block's bus across ranks, in place in
+ * device memory, on a second stream ordered after the block's kernel. */
+int smx_bank_allreduce_async(smx_bank *b, int n);
+/* Copy the (reduced) bus to the host and convert as linux/synth.c:180. */
+int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n);
+
+/* ======================================================================== */
+/* 3. Carry-out PDM bank: stm32f103/mod_pdm.c:198-286                       */
+/* ======================================================================== */
+typedef struct smx_pdm smx_pdm;
+smx_pdm *smx_pdm_create(uint32_t n_channels, int device);
+void     smx_pdm_destroy(smx_pdm *p);
+/* pdm_init (mod_pdm.c:296-326): every setpoint 0x40000000, channel 0
+ * 2000000000, accumulators 0. */
+int smx_pdm_init(smx_pdm *p);
+/* mod_synth.c:104-111 (SETPOINT): -2 if chan out of range. */
+int smx_pdm_set_setpoint(smx_pdm *p, uint32_t chan, uint32_t val);
+uint32_t pdm_safe_setpoint(uint32_t setpoint);       /* mod_pdm.c:101-107 */
+int smx_pdm_load(smx_pdm *p, const uint32_t *setpoint, const uint32_t *accu);
+int smx_pdm_read(smx_pdm *p, uint32_t *setpoint, uint32_t *accu);
+/* n_ticks of the PDM ISR body (mod_pdm.c:259-264).  dither: host
+ * uint32[n_ticks] or NULL (= 0); the value is shared by all channels within
+ * a tick, as in the reference, and is added unmasked (the reference masks
+ * its generator with 0x0FFFFFFF, mod_pdm.c:261; the generator itself is
+ * uc_tools' and is not part of this library).  bits: host
+ * uint32[n_ticks * ceil(n/32)] or NULL: tick-major pulse words, channel c in
+ * bit (c&31) of word (c>>5).  Synchronous. */
+int smx_pdm_tick_n(smx_pdm *p, uint32_t n_ticks, const uint32_t *dither,
+                   uint32_t *bits);
+/* Asynchronous, output stays in HBM (smx_pdm_bits_dev). */
+int   smx_pdm_tick_n_async(smx_pdm *p, uint32_t n_ticks, int with_dither);
+void *smx_pdm_bits_dev(smx_pdm *p);
+void *smx_pdm_dither_dev(smx_pdm *p, uint32_t n_ticks);  /* device uint32[n_ticks] */
+int   smx_pdm_sync(smx_pdm *p);
+int   smx_pdm_timer_start(smx_pdm *p);
+int   smx_pdm_timer_stop(smx_pdm *p, float *ms);
+/* The reference's GPIO BSRR word (mod_pdm.c:271-286) from one tick's pulse
+ * word, for nb <= 12 channels on pins 4.. */
+uint32_t smx_pdm_bsrr_word(uint32_t pulse_bits, uint32_t nb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

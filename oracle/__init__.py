@@ -1,0 +1,109 @@
+"""ctypes loader for the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this package.  The product (synth_tools_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "synth_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class PwmBank(C.Structure):
+    _fields_ = [("n", C.c_uint32),
+                ("setpoint", C.c_void_p), ("pos0", C.c_void_p), ("vel0", C.c_void_p),
+                ("pos1", C.c_void_p), ("vel1", C.c_void_p),
+                ("s1", C.c_void_p), ("s2", C.c_void_p),
+                ("div_count", C.c_uint32), ("div_log", C.c_uint32), ("out_shift", C.c_uint32)]
+
+
+class Pmeas(C.Structure):
+    _fields_ = [("log_max", C.c_uint32), ("write", C.c_uint32), ("read", C.c_uint32),
+                ("avg", C.c_uint32 * 2), ("num_pub", C.c_uint32 * 2),
+                ("num", C.c_uint32), ("accu", C.c_uint32), ("last_cc", C.c_uint32),
+                ("sub", C.c_uint32)]
+
+
+class PolyBank(C.Structure):
+    _fields_ = [("n", C.c_uint32)] + [(k, C.c_void_p) for k in
+                ("inc", "phase", "y", "a", "level", "stage", "gate", "ar", "dr", "sl", "rr", "pan")]
+
+
+def load():
+    lib = C.CDLL(build())
+    lib.orc_note_tab.argtypes = [_u32p]
+    lib.orc_midi_tab.argtypes = [C.c_int]; lib.orc_midi_tab.restype = C.c_uint8
+    lib.orc_note_to_inc.argtypes = [C.c_int]; lib.orc_note_to_inc.restype = C.c_uint32
+    lib.orc_voice_alloc.argtypes = [_u32p, C.c_uint32]; lib.orc_voice_alloc.restype = C.c_int
+    lib.orc_note_on.argtypes = [_i32p, _u32p, C.c_uint32, C.c_int]
+    lib.orc_note_off.argtypes = [_i32p, _u32p, C.c_uint32, C.c_int]
+    lib.orc_sum_tick_saw.argtypes = [_u32p, _u32p, C.c_uint32]; lib.orc_sum_tick_saw.restype = C.c_int32
+    lib.orc_bus_to_float.argtypes = [C.c_int32]; lib.orc_bus_to_float.restype = C.c_float
+    lib.orc_sum_tick_square.argtypes = [_u32p, _u32p, C.c_uint32]; lib.orc_sum_tick_square.restype = C.c_float
+    lib.orc_synth_run.argtypes = [_u32p, _u32p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_midi_event.argtypes = [_i32p, _u32p, C.c_uint32, _u8p, C.c_size_t]
+    lib.orc_pdm_tick.argtypes = [_u32p, _u32p, C.c_uint32, C.c_uint32, _u32p]
+    lib.orc_pdm_run.argtypes = [_u32p, _u32p, C.c_uint32, C.c_void_p, C.c_uint32, _u32p]
+    lib.orc_pdm_bsrr.argtypes = [_u32p, _u32p, C.c_uint32, C.c_uint32]; lib.orc_pdm_bsrr.restype = C.c_uint32
+    lib.orc_pwm_update.argtypes = [_u32p, C.c_uint32]; lib.orc_pwm_update.restype = C.c_uint32
+    lib.orc_pdm1_update.argtypes = [_u32p, C.c_uint32, C.c_uint32]; lib.orc_pdm1_update.restype = C.c_uint32
+    for k in (2, 3, 4):
+        f = getattr(lib, "orc_pdm%d_update" % k)
+        f.argtypes = [_u32p, C.c_uint32, C.c_uint32, C.c_uint32]; f.restype = C.c_uint32
+    lib.orc_pwm_bank_run.argtypes = [C.POINTER(PwmBank), C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.orc_pmeas_update.argtypes = [C.POINTER(Pmeas), C.c_uint32]
+    lib.orc_osc_event.argtypes = [C.POINTER(Pmeas), C.c_uint32]
+    lib.orc_acc_update.argtypes = [_u32p, C.c_uint32]
+    lib.orc_edge_update.argtypes = [_u32p, _u32p, C.c_uint32]
+    lib.orc_poly_run.argtypes = [C.POINTER(PolyBank), _i32p, C.c_int]
+    return lib
+
+
+def load_ref_pdm():
+    """The reference's own pdm.h, compiled into oracle/_ref (None if absent)."""
+    so = os.path.join(_HERE, "_ref", "libref_pdm.so")
+    if os.path.isdir("/root/reference"):
+        build()
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    lib.ref_pdm1_update.argtypes = [_u32p, C.c_uint32, C.c_uint32]; lib.ref_pdm1_update.restype = C.c_uint32
+    for k in (2, 3, 4):
+        f = getattr(lib, "ref_pdm%d_update" % k)
+        f.argtypes = [_u32p, C.c_uint32, C.c_uint32, C.c_uint32]; f.restype = C.c_uint32
+    return lib
+
+
+# ---- convenience wrappers ---------------------------------------------------
+def synth_run(lib, inc, state, nframes, want_vec=True):
+    """Runs orc_synth_run in place on state; returns (bus int32[n], vec f32[n])."""
+    bus = np.zeros(nframes, np.int32)
+    vec = np.zeros(nframes, np.float32)
+    lib.orc_synth_run(inc, state, len(inc), vec.ctypes.data if want_vec else None,
+                      bus.ctypes.data, nframes)
+    return bus, vec
+
+
+def pdm_run(lib, setpoint, accu, nticks, dither=None):
+    words = (len(setpoint) + 31) // 32
+    bits = np.zeros(nticks * words, np.uint32)
+    d = None if dither is None else np.ascontiguousarray(dither, np.uint32)
+    lib.orc_pdm_run(setpoint, accu, len(setpoint), None if d is None else d.ctypes.data, nticks, bits)
+    return bits.reshape(nticks, words)

@@ -1,0 +1,124 @@
+/* synth_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the per-sample voice loops of zwizwa/synth_tools,
+ * widened from the reference's compile-time voice/channel counts to N.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this.  The product path (synth_tools_amd/csrc) never links, calls or
+ * falls back to anything in oracle/.
+ *
+ * Parity pinning (see DESIGN.md "Oracle"):
+ *   - pdm1..pdm4: checked against the REAL reference header stm32f103/pdm.h,
+ *     compiled from where it lies (oracle/_ref, see oracle/Makefile).
+ *   - carry-out PDM: checked against the only known-answer the reference
+ *     holds, the X=3 row of the comment at stm32f103/mod_pdm.c:43-47.
+ *   - synth_run / note_to_inc: restatement of linux/synth.c (unbuildable
+ *     here: needs uc_tools macros.h + JACK headers).  Checked against the
+ *     known-answers SURVEY.md Appendix A.2 recorded from the reference.
+ *   - mod_pdm_pwm.c / mod_controlrate.c / pmeas.h / mod_osc.c: restatement
+ *     only (ARM + uc_tools HAL; unbuildable) -- "parity unpinned".
+ *   - dither (uc_tools xorshift.h, absent): always an explicit input.
+ *   - poly voice (LPF+ADSR): build-defined extension, no reference.
+ *
+ * All arithmetic is uint32_t modular; signed values are derived by cast and
+ * shifted arithmetically (gcc semantics, which the reference relies on).
+ * Build with -fwrapv -ffp-contract=off.
+ */
+#ifndef SYNTH_ORACLE_H
+#define SYNTH_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- linux/synth.c ------------------------------------------------------ */
+void     orc_note_tab(uint32_t out[12]);               /* linux/synth.c:78-98  */
+uint8_t  orc_midi_tab(int note);                       /* linux/synth.c:100-115 */
+uint32_t orc_note_to_inc(int note);                    /* linux/synth.c:118-125 */
+int      orc_voice_alloc(const uint32_t *inc, uint32_t n);            /* :145-154 */
+void     orc_note_on (int *note2voice, uint32_t *inc, uint32_t n, int note); /* :156-160 */
+void     orc_note_off(int *note2voice, uint32_t *inc, uint32_t n, int note); /* :161-165 */
+int32_t  orc_sum_tick_saw(const uint32_t *inc, uint32_t *state, uint32_t n); /* :169-181 int part */
+float    orc_bus_to_float(int32_t sum);                /* :180 scale            */
+float    orc_sum_tick_square(const uint32_t *inc, uint32_t *state, uint32_t n); /* :182-195 */
+/* synth_run over n voices; vec and/or bus may be NULL.  linux/synth.c:196-202 */
+void     orc_synth_run(const uint32_t *inc, uint32_t *state, uint32_t n,
+                       float *vec, int32_t *bus, int nframes);
+/* process_midi dispatch for one event.  linux/synth.c:236-258 */
+void     orc_midi_event(int *note2voice, uint32_t *inc, uint32_t n,
+                        const uint8_t *msg, size_t size);
+
+/* ---- stm32f103/mod_pdm.c ------------------------------------------------ */
+/* One tick of the carry-out bank.  bits[] gets ceil(n/32) words, channel c ->
+ * bit (c & 31) of word (c >> 5).  mod_pdm.c:214-244, 259-264 */
+void     orc_pdm_tick(const uint32_t *setpoint, uint32_t *accu, uint32_t n,
+                      uint32_t dither, uint32_t *bits);
+/* T ticks, tick-major output bits[t*words + w]; dither may be NULL (=0) else
+ * dither[t] (already masked by the caller; mod_pdm.c:261 masks 0x0FFFFFFF). */
+void     orc_pdm_run(const uint32_t *setpoint, uint32_t *accu, uint32_t n,
+                     const uint32_t *dither, uint32_t nticks, uint32_t *bits);
+/* The reference's GPIO word for nb <= 12 channels.  mod_pdm.c:271-286 */
+uint32_t orc_pdm_bsrr(const uint32_t *setpoint, uint32_t *accu, uint32_t nb,
+                      uint32_t dither);
+/* mod_pdm.c:167-175.  Returns duty, advances *phase. */
+uint32_t orc_pwm_update(uint32_t *phase, uint32_t speed);
+
+/* ---- stm32f103/pdm.h ---------------------------------------------------- */
+uint32_t orc_pdm1_update(uint32_t *s, uint32_t input, uint32_t out_shift);
+uint32_t orc_pdm2_update(uint32_t *s, uint32_t input, uint32_t out_shift, uint32_t dither);
+uint32_t orc_pdm3_update(uint32_t *s, uint32_t input, uint32_t out_shift, uint32_t dither);
+uint32_t orc_pdm4_update(uint32_t *s, uint32_t input, uint32_t out_shift, uint32_t dither);
+
+/* ---- stm32f103/mod_pdm_pwm.c + mod_controlrate.c ------------------------ */
+/* SoA noise-shaped PWM bank of n channels (reference: 3, AoS).
+ * Per tick (mod_pdm_pwm.c:123-143): if div_count==0 { line0 = line1; control
+ * update (mod_controlrate.c:28-40) runs after this tick }; pos0 += vel0;
+ * duty = pdm2_update(s, pos0, out_shift, dither[t]); div_count =
+ * (div_count+1) % (1<<div_log).  duty output is tick-major uint8
+ * duty[t*n + c] (out_shift=24 -> 8 bit, mod_pdm_pwm.c:115). */
+struct orc_pwm_bank {
+    uint32_t n;
+    uint32_t *setpoint;
+    uint32_t *pos0; int32_t *vel0;   /* line[0] */
+    uint32_t *pos1; int32_t *vel1;   /* line[1] */
+    uint32_t *s1, *s2;               /* struct pdm2 */
+    uint32_t div_count;
+    uint32_t div_log;                /* CONTROL_DIV_LOG = 12 */
+    uint32_t out_shift;              /* 32 - PDM_DIV_LOG = 24 */
+};
+void orc_pwm_bank_run(struct orc_pwm_bank *b, const uint32_t *dither,
+                      uint32_t nticks, uint8_t *duty);
+
+/* ---- stm32f103/pmeas.h + mod_osc.c -------------------------------------- */
+struct orc_pmeas {
+    uint32_t log_max, write, read;
+    uint32_t avg[2], num_pub[2];
+    uint32_t num, accu, last_cc;
+    uint32_t sub;                    /* sub-osc bit, mod_osc.c:65 */
+};
+void orc_pmeas_update(struct orc_pmeas *p, uint32_t cc);     /* pmeas.h:64-100 */
+void orc_osc_event(struct orc_pmeas *p, uint32_t cc);        /* mod_osc.c:47-74 */
+
+/* ---- generic/cproc.h ---------------------------------------------------- */
+void orc_acc_update(uint32_t *out, uint32_t in);                     /* :142-144 */
+void orc_edge_update(uint32_t *out, uint32_t *last, uint32_t in);    /* :152-155 */
+
+/* ---- poly voice: BUILD-DEFINED EXTENSION (no reference counterpart) ----- */
+/* Stage codes */
+enum { ORC_ENV_IDLE = 0, ORC_ENV_A = 1, ORC_ENV_D = 2, ORC_ENV_S = 3, ORC_ENV_R = 4 };
+struct orc_poly_bank {
+    uint32_t n;
+    uint32_t *inc, *phase;           /* saw phasor, as linux/synth.c */
+    float    *y, *a;                 /* 1-pole LPF: t=x-y; y=y+a*t   */
+    uint32_t *level, *stage;         /* ADSR level (u32), stage code  */
+    uint32_t *gate;                  /* 0/1, sampled at block start   */
+    uint32_t *ar, *dr, *sl, *rr;     /* per-sample rates, sustain lvl */
+    uint32_t *pan;                   /* pl | pr<<16, each 0..256      */
+};
+void orc_poly_run(struct orc_poly_bank *b, int32_t *bus_lr /*[nframes*2]*/,
+                  int nframes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

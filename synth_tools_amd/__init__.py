@@ -1,0 +1,247 @@
+"""synth_tools_amd -- ctypes binding of libsynth_mi355x.so (include/synth_mi355x.h).
+
+This is a thin test/bench driver over the C-ABI; the product is the shared
+library.  There is no Python or CPU implementation of any compute path here:
+if the HIP library is missing, import fails; if no GPU is visible, every
+compute call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsynth_mi355x.so")
+
+_u32 = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f32 = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+UNIQUE_ID_BYTES = 128
+
+
+class SmxError(RuntimeError):
+    pass
+
+
+class Voice(C.Structure):            # linux/synth.c:31-34
+    _fields_ = [("note_inc", C.c_uint32), ("note_state", C.c_uint32)]
+
+
+class Synth(C.Structure):            # linux/synth.c:35-38
+    _fields_ = [("note2voice", C.c_int * 128), ("voice", Voice * 64)]
+
+
+# Every symbol include/synth_mi355x.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+ABI = [
+    ("smx_last_error", C.c_char_p, []),
+    ("smx_device_count", C.c_int, []),
+    ("smx_version", C.c_int, []),
+    ("synth_note_on", None, [C.POINTER(Synth), C.c_int]),
+    ("synth_note_off", None, [C.POINTER(Synth), C.c_int]),
+    ("synth_init", None, [C.POINTER(Synth)]),
+    ("synth_run", None, [C.POINTER(Synth), _f32, C.c_int]),
+    ("note_to_inc", C.c_uint32, [C.c_int]),
+    ("voice_alloc", C.c_int, [C.POINTER(Synth)]),
+    ("synth_midi_event", None, [C.POINTER(Synth), _u8, C.c_size_t]),
+    ("smx_bank_create", _P, [C.c_uint32, C.c_int]),
+    ("smx_bank_destroy", None, [_P]),
+    ("smx_bank_voices", C.c_uint32, [_P]),
+    ("smx_bank_load", C.c_int, [_P, _P, _P]),
+    ("smx_bank_read", C.c_int, [_P, _P, _P]),
+    ("smx_bank_note_on", C.c_int, [_P, C.c_int]),
+    ("smx_bank_note_off", C.c_int, [_P, C.c_int]),
+    ("smx_bank_run", C.c_int, [_P, _P, _P, C.c_int]),
+    ("smx_bank_run_async", C.c_int, [_P, C.c_int]),
+    ("smx_bank_bus_dev", _P, [_P]),
+    ("smx_bank_sync", C.c_int, [_P]),
+    ("smx_bank_run_square", C.c_int, [_P, _P, C.c_int]),
+    ("smx_bank_timer_start", C.c_int, [_P]),
+    ("smx_bank_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("smx_comm_unique_id", C.c_int, [_u8]),
+    ("smx_bank_comm_init", C.c_int, [_P, C.c_int, C.c_int, _u8]),
+    ("smx_bank_allreduce_async", C.c_int, [_P, C.c_int]),
+    ("smx_bank_fetch", C.c_int, [_P, _P, _P, C.c_int]),
+    ("smx_pdm_create", _P, [C.c_uint32, C.c_int]),
+    ("smx_pdm_destroy", None, [_P]),
+    ("smx_pdm_init", C.c_int, [_P]),
+    ("smx_pdm_set_setpoint", C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    ("pdm_safe_setpoint", C.c_uint32, [C.c_uint32]),
+    ("smx_pdm_load", C.c_int, [_P, _P, _P]),
+    ("smx_pdm_read", C.c_int, [_P, _P, _P]),
+    ("smx_pdm_tick_n", C.c_int, [_P, C.c_uint32, _P, _P]),
+    ("smx_pdm_tick_n_async", C.c_int, [_P, C.c_uint32, C.c_int]),
+    ("smx_pdm_bits_dev", _P, [_P]),
+    ("smx_pdm_dither_dev", _P, [_P, C.c_uint32]),
+    ("smx_pdm_sync", C.c_int, [_P]),
+    ("smx_pdm_timer_start", C.c_int, [_P]),
+    ("smx_pdm_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("smx_pdm_bsrr_word", C.c_uint32, [C.c_uint32, C.c_uint32]),
+]
+ABI_DATA = ["midi_tab"]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (never a fallback: raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SmxError("%s is missing: run `python -m synth_tools_amd.build` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in ABI:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rv, what):
+    if rv != 0:
+        raise SmxError("%s failed (%d): %s" % (what, rv, lib().smx_last_error().decode()))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class SawBank:
+    """N-voice saw bank (linux/synth.c:27-208 widened), state resident in HBM."""
+
+    def __init__(self, n_voices, device=0):
+        self._h = lib().smx_bank_create(n_voices, device)
+        if not self._h:
+            raise SmxError("smx_bank_create: " + lib().smx_last_error().decode())
+        self.n = n_voices
+
+    def close(self):
+        if self._h:
+            lib().smx_bank_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def load(self, inc=None, state=None):
+        inc = None if inc is None else np.ascontiguousarray(inc, np.uint32)
+        state = None if state is None else np.ascontiguousarray(state, np.uint32)
+        for a in (inc, state):
+            assert a is None or a.shape == (self.n,)
+        _check(lib().smx_bank_load(self._h, _ptr(inc), _ptr(state)), "smx_bank_load")
+
+    def read(self):
+        inc = np.empty(self.n, np.uint32)
+        state = np.empty(self.n, np.uint32)
+        _check(lib().smx_bank_read(self._h, _ptr(inc), _ptr(state)), "smx_bank_read")
+        return inc, state
+
+    def note_on(self, note):
+        _check(lib().smx_bank_note_on(self._h, note), "smx_bank_note_on")
+
+    def note_off(self, note):
+        _check(lib().smx_bank_note_off(self._h, note), "smx_bank_note_off")
+
+    def run(self, n):
+        """synth_run for n frames -> (bus int32[n], vec float32[n])."""
+        vec = np.empty(n, np.float32)
+        bus = np.empty(n, np.int32)
+        _check(lib().smx_bank_run(self._h, _ptr(vec), _ptr(bus), n), "smx_bank_run")
+        return bus, vec
+
+    def run_square(self, n):
+        vec = np.empty(n, np.float32)
+        _check(lib().smx_bank_run_square(self._h, _ptr(vec), n), "smx_bank_run_square")
+        return vec
+
+    def run_async(self, n):
+        _check(lib().smx_bank_run_async(self._h, n), "smx_bank_run_async")
+
+    def sync(self):
+        _check(lib().smx_bank_sync(self._h), "smx_bank_sync")
+
+    def fetch(self, n):
+        vec = np.empty(n, np.float32)
+        bus = np.empty(n, np.int32)
+        _check(lib().smx_bank_fetch(self._h, _ptr(vec), _ptr(bus), n), "smx_bank_fetch")
+        return bus, vec
+
+    def timer_start(self):
+        _check(lib().smx_bank_timer_start(self._h), "smx_bank_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _check(lib().smx_bank_timer_stop(self._h, C.byref(ms)), "smx_bank_timer_stop")
+        return ms.value
+
+    def comm_init(self, rank, nranks, unique_id):
+        uid = np.ascontiguousarray(unique_id, np.uint8)
+        assert uid.shape == (UNIQUE_ID_BYTES,)
+        _check(lib().smx_bank_comm_init(self._h, rank, nranks, uid), "smx_bank_comm_init")
+
+    def allreduce_async(self, n):
+        _check(lib().smx_bank_allreduce_async(self._h, n), "smx_bank_allreduce_async")
+
+
+def comm_unique_id():
+    uid = np.zeros(UNIQUE_ID_BYTES, np.uint8)
+    _check(lib().smx_comm_unique_id(uid), "smx_comm_unique_id")
+    return uid
+
+
+class PdmBank:
+    """N-channel carry-out PDM bank (stm32f103/mod_pdm.c:198-286)."""
+
+    def __init__(self, n_channels, device=0):
+        self._h = lib().smx_pdm_create(n_channels, device)
+        if not self._h:
+            raise SmxError("smx_pdm_create: " + lib().smx_last_error().decode())
+        self.n = n_channels
+        self.words = (n_channels + 31) // 32
+
+    def close(self):
+        if self._h:
+            lib().smx_pdm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def init(self):
+        _check(lib().smx_pdm_init(self._h), "smx_pdm_init")
+
+    def set_setpoint(self, chan, val):
+        return lib().smx_pdm_set_setpoint(self._h, chan, val)
+
+    def load(self, setpoint=None, accu=None):
+        setpoint = None if setpoint is None else np.ascontiguousarray(setpoint, np.uint32)
+        accu = None if accu is None else np.ascontiguousarray(accu, np.uint32)
+        _check(lib().smx_pdm_load(self._h, _ptr(setpoint), _ptr(accu)), "smx_pdm_load")
+
+    def read(self):
+        sp = np.empty(self.n, np.uint32)
+        ac = np.empty(self.n, np.uint32)
+        _check(lib().smx_pdm_read(self._h, _ptr(sp), _ptr(ac)), "smx_pdm_read")
+        return sp, ac
+
+    def tick_n(self, n_ticks, dither=None, want_bits=True):
+        d = None if dither is None else np.ascontiguousarray(dither, np.uint32)
+        bits = np.empty((n_ticks, self.words), np.uint32) if want_bits else None
+        _check(lib().smx_pdm_tick_n(self._h, n_ticks, _ptr(d), _ptr(bits)), "smx_pdm_tick_n")
+        return bits
+
+    def tick_n_async(self, n_ticks, with_dither=False):
+        _check(lib().smx_pdm_tick_n_async(self._h, n_ticks, int(with_dither)), "smx_pdm_tick_n_async")
+
+    def sync(self):
+        _check(lib().smx_pdm_sync(self._h), "smx_pdm_sync")
+
+    def timer_start(self):
+        _check(lib().smx_pdm_timer_start(self._h), "smx_pdm_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _check(lib().smx_pdm_timer_stop(self._h, C.byref(ms)), "smx_pdm_timer_stop")
+        return ms.value

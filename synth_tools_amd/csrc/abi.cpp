@@ -1,0 +1,715 @@
+// abi.cpp -- the C-ABI of libsynth_mi355x.so (include/synth_mi355x.h).
+//
+// Host side of the drop-in boundary: owns HBM-resident struct-of-arrays voice
+// state, the HIP streams/events, the note allocator (linux/synth.c:145-165
+// semantics widened to N voices) and the RCCL communicator for the
+// multi-GPU bus sum.  No CPU compute fallback exists: every compute entry
+// point needs a HIP device and fails with SMX_E_NOGPU otherwise.
+#include "smx_common.h"
+#include <rccl/rccl.h>
+#include <cstdarg>
+#include <vector>
+#include <mutex>
+
+namespace smx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// First-free search over N voices in O(log64 N): the reference scans its 64
+// voices linearly (linux/synth.c:147-149); a bank has up to 2^32.
+class FreeMap {
+public:
+    void reset(uint32_t n, bool all_free)
+    {
+        n_ = n;
+        levels_.clear();
+        uint32_t bits = n;
+        do {
+            uint32_t words = (bits + 63) / 64;
+            levels_.emplace_back(words, 0ull);
+            bits = words;
+        } while (bits > 1);
+        if (all_free)
+            for (uint32_t v = 0; v < n; v++) set_leaf_only(v);
+        rebuild_summaries();
+    }
+    void load(const uint32_t *inc, uint32_t n)
+    {
+        reset(n, false);
+        for (uint32_t v = 0; v < n; v++)
+            if (inc[v] == 0) set_leaf_only(v);
+        rebuild_summaries();
+    }
+    void set_free(uint32_t v, bool is_free)
+    {
+        uint32_t idx = v;
+        for (size_t l = 0; l < levels_.size(); l++) {
+            uint64_t &w = levels_[l][idx >> 6];
+            const uint64_t bit = 1ull << (idx & 63);
+            if (is_free) w |= bit; else w &= ~bit;
+            const bool any = w != 0;
+            idx >>= 6;
+            if (l + 1 < levels_.size()) {
+                const bool was = (levels_[l + 1][idx >> 6] >> (idx & 63)) & 1;
+                if (was == any) break;
+                is_free = any;
+            }
+        }
+    }
+    // index of the first free voice, or -1
+    int64_t first_free() const
+    {
+        if (levels_.empty() || levels_.back()[0] == 0) return -1;
+        uint32_t idx = 0;
+        for (size_t l = levels_.size(); l-- > 0;) {
+            const uint64_t w = levels_[l][idx];
+            idx = idx * 64 + (uint32_t)__builtin_ctzll(w);
+        }
+        return idx < n_ ? (int64_t)idx : -1;
+    }
+private:
+    void set_leaf_only(uint32_t v) { levels_[0][v >> 6] |= 1ull << (v & 63); }
+    void rebuild_summaries()
+    {
+        for (size_t l = 1; l < levels_.size(); l++) {
+            std::fill(levels_[l].begin(), levels_[l].end(), 0ull);
+            for (size_t i = 0; i < levels_[l - 1].size(); i++)
+                if (levels_[l - 1][i]) levels_[l][i >> 6] |= 1ull << (i & 63);
+        }
+    }
+    uint32_t n_ = 0;
+    std::vector<std::vector<uint64_t>> levels_;
+};
+
+}  // namespace smx
+
+using smx::set_error;
+
+// ---------------------------------------------------------------------------
+// note tables: linux/synth.c:69-125.  The reference folds the top octave at
+// compile time in double; the same double products evaluated at load time
+// give the same IEEE results.
+// ---------------------------------------------------------------------------
+static uint32_t g_note_tab[12];
+extern "C" const uint8_t midi_tab[128] = {
+#define SMX_NOTE(o, n) (uint8_t)((((o) & 15) << 4) | ((n) & 15))
+#define SMX_OCT(o)                                                                     \
+    SMX_NOTE(o, 0), SMX_NOTE(o, 1), SMX_NOTE(o, 2), SMX_NOTE(o, 3), SMX_NOTE(o, 4),    \
+    SMX_NOTE(o, 5), SMX_NOTE(o, 6), SMX_NOTE(o, 7), SMX_NOTE(o, 8), SMX_NOTE(o, 9),    \
+    SMX_NOTE(o, 10), SMX_NOTE(o, 11)
+    SMX_NOTE(10, 4), SMX_NOTE(10, 5), SMX_NOTE(10, 6), SMX_NOTE(10, 7),
+    SMX_NOTE(10, 8), SMX_NOTE(10, 9), SMX_NOTE(10, 10), SMX_NOTE(10, 11),
+    SMX_OCT(9), SMX_OCT(8), SMX_OCT(7), SMX_OCT(6), SMX_OCT(5),
+    SMX_OCT(4), SMX_OCT(3), SMX_OCT(2), SMX_OCT(1), SMX_OCT(0),
+#undef SMX_OCT
+#undef SMX_NOTE
+};
+static std::once_flag g_tab_once;
+static void init_note_tab()
+{
+    const double semitone_down = 0.9438743126816935;          // 2^(-1/12)
+    double x = (12543.853951415975 / 48000.0) * 4294967296.0;  // MIDI 127 @48 kHz, 32-bit phasor
+    for (int i = 11; i >= 0; i--) {
+        g_note_tab[i] = (uint32_t)x;
+        x = semitone_down * x;
+    }
+}
+
+extern "C" phasor_t note_to_inc(int note)
+{
+    std::call_once(g_tab_once, init_note_tab);
+    const int on = midi_tab[note & 127];
+    return g_note_tab[on & 15] >> (on >> 4);
+}
+
+// ---------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------
+extern "C" const char *smx_last_error(void) { return smx::g_err; }
+extern "C" int smx_version(void) { return 1; }
+extern "C" int smx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// saw bank
+// ---------------------------------------------------------------------------
+struct smx_bank {
+    uint32_t n = 0, n_pad = 0;
+    int device = 0;
+    uint32_t *d_inc = nullptr;
+    uint32_t *d_state[2] = {nullptr, nullptr};   // ping-pong (saw_bank.hip)
+    int cur = 0;
+    int32_t *d_bus[2] = {nullptr, nullptr};      // double-buffered for the all-reduce
+    int bus_cur = 0;
+    uint32_t bus_cap = 0;
+    int32_t *h_bus = nullptr;                    // pinned
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_kernel[2] = {nullptr, nullptr};   // kernel of bus[i] finished
+    hipEvent_t ev_comm[2] = {nullptr, nullptr};     // all-reduce of bus[i] finished
+    bool comm_pending[2] = {false, false};
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    int note2voice[128];
+    smx::FreeMap free_map;
+};
+
+static int bank_ensure_bus(smx_bank *b, uint32_t n)
+{
+    if (n <= b->bus_cap) return SMX_OK;
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
+    const uint32_t cap = smx::round_up(n < 4096 ? 4096 : n, 4096);
+    for (int i = 0; i < 2; i++) {
+        if (b->d_bus[i]) SMX_HIP(hipFree(b->d_bus[i]));
+        b->d_bus[i] = nullptr;
+        SMX_HIP(hipMalloc((void **)&b->d_bus[i], (size_t)cap * 4));
+    }
+    if (b->h_bus) SMX_HIP(hipHostFree(b->h_bus));
+    b->h_bus = nullptr;
+    SMX_HIP(hipHostMalloc((void **)&b->h_bus, (size_t)cap * 4, hipHostMallocDefault));
+    b->bus_cap = cap;
+    return SMX_OK;
+}
+
+extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
+{
+    if (n_voices == 0) { set_error("smx_bank_create: n_voices == 0"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("smx_bank_create: no HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { set_error("smx_bank_create: device %d of %d", device, ndev); return nullptr; }
+    smx_bank *b = new smx_bank();
+    b->n = n_voices;
+    b->n_pad = smx::round_up(n_voices, 1024);
+    b->device = device;
+    auto fail = [&](const char *what, hipError_t e) -> smx_bank * {
+        set_error("smx_bank_create: %s: %s", what, hipGetErrorString(e));
+        smx_bank_destroy(b);
+        return nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    const size_t bytes = (size_t)b->n_pad * 4;
+    if ((e = hipMalloc((void **)&b->d_inc, bytes)) != hipSuccess) return fail("hipMalloc inc", e);
+    for (int i = 0; i < 2; i++)
+        if ((e = hipMalloc((void **)&b->d_state[i], bytes)) != hipSuccess) return fail("hipMalloc state", e);
+    if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+    if ((e = hipEventCreate(&b->ev_t0)) != hipSuccess) return fail("event", e);
+    if ((e = hipEventCreate(&b->ev_t1)) != hipSuccess) return fail("event", e);
+    for (int i = 0; i < 2; i++) {
+        if ((e = hipEventCreateWithFlags(&b->ev_kernel[i], hipEventDisableTiming)) != hipSuccess) return fail("event", e);
+        if ((e = hipEventCreateWithFlags(&b->ev_comm[i], hipEventDisableTiming)) != hipSuccess) return fail("event", e);
+    }
+    // synth_init: bzero (linux/synth.c:204-206); padding voices stay off forever
+    if ((e = hipMemsetAsync(b->d_inc, 0, bytes, b->stream)) != hipSuccess) return fail("memset", e);
+    for (int i = 0; i < 2; i++)
+        if ((e = hipMemsetAsync(b->d_state[i], 0, bytes, b->stream)) != hipSuccess) return fail("memset", e);
+    if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return fail("sync", e);
+    memset(b->note2voice, 0, sizeof(b->note2voice));
+    b->free_map.reset(b->n, true);
+    if (bank_ensure_bus(b, 4096) != SMX_OK) { smx_bank_destroy(b); return nullptr; }
+    return b;
+}
+
+extern "C" void smx_bank_destroy(smx_bank *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->comm_stream) (void)hipStreamSynchronize(b->comm_stream);
+    if (b->comm) (void)ncclCommDestroy(b->comm);
+    if (b->d_inc) (void)hipFree(b->d_inc);
+    for (int i = 0; i < 2; i++) {
+        if (b->d_state[i]) (void)hipFree(b->d_state[i]);
+        if (b->d_bus[i]) (void)hipFree(b->d_bus[i]);
+        if (b->ev_kernel[i]) (void)hipEventDestroy(b->ev_kernel[i]);
+        if (b->ev_comm[i]) (void)hipEventDestroy(b->ev_comm[i]);
+    }
+    if (b->h_bus) (void)hipHostFree(b->h_bus);
+    if (b->ev_t0) (void)hipEventDestroy(b->ev_t0);
+    if (b->ev_t1) (void)hipEventDestroy(b->ev_t1);
+    if (b->comm_stream) (void)hipStreamDestroy(b->comm_stream);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+extern "C" uint32_t smx_bank_voices(const smx_bank *b) { return b ? b->n : 0; }
+
+extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *state)
+{
+    if (!b) { set_error("smx_bank_load: null bank"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (inc) {
+        SMX_HIP(hipMemcpy(b->d_inc, inc, (size_t)b->n * 4, hipMemcpyHostToDevice));
+        b->free_map.load(inc, b->n);
+    }
+    if (state)
+        SMX_HIP(hipMemcpy(b->d_state[b->cur], state, (size_t)b->n * 4, hipMemcpyHostToDevice));
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state)
+{
+    if (!b) { set_error("smx_bank_read: null bank"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (inc) SMX_HIP(hipMemcpy(inc, b->d_inc, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    if (state) SMX_HIP(hipMemcpy(state, b->d_state[b->cur], (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+static int bank_set_inc(smx_bank *b, uint32_t v, uint32_t inc)
+{
+    SMX_HIP(hipSetDevice(b->device));
+    // pageable 4-byte source: hipMemcpyAsync stages it before returning
+    SMX_HIP(hipMemcpyAsync(b->d_inc + v, &inc, 4, hipMemcpyHostToDevice, b->stream));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    b->free_map.set_free(v, inc == 0);
+    return SMX_OK;
+}
+
+// linux/synth.c:156-160 over N voices
+extern "C" int smx_bank_note_on(smx_bank *b, int note)
+{
+    if (!b) { set_error("smx_bank_note_on: null bank"); return SMX_E_ARG; }
+    if (note < 0) { set_error("smx_bank_note_on: note %d < 0", note); return SMX_E_ARG; }
+    int64_t v = b->free_map.first_free();
+    if (v < 0) v = 0;                                  // steal voice 0 (:150-153)
+    b->note2voice[note % 128] = (int)v;
+    return bank_set_inc(b, (uint32_t)v, note_to_inc(note % 128));
+}
+
+// linux/synth.c:161-165 over N voices
+extern "C" int smx_bank_note_off(smx_bank *b, int note)
+{
+    if (!b) { set_error("smx_bank_note_off: null bank"); return SMX_E_ARG; }
+    if (note < 0) { set_error("smx_bank_note_off: note %d < 0", note); return SMX_E_ARG; }
+    const int v = b->note2voice[note % 128];
+    b->note2voice[note % 128] = 0;
+    return bank_set_inc(b, (uint32_t)v, 0);
+}
+
+extern "C" int smx_bank_run_async(smx_bank *b, int n)
+{
+    if (!b || n <= 0) { set_error("smx_bank_run_async: bad args"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    int rv = bank_ensure_bus(b, (uint32_t)n);
+    if (rv) return rv;
+    const int bi = b->bus_cur ^ 1;
+    // the buffer being recycled may still be feeding an all-reduce
+    if (b->comm_pending[bi]) {
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
+        b->comm_pending[bi] = false;
+    }
+    SMX_HIP(hipMemsetAsync(b->d_bus[bi], 0, (size_t)n * 4, b->stream));
+    rv = smx::launch_saw_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1], b->d_bus[bi],
+                              b->n_pad, (uint32_t)n, b->stream);
+    if (rv) return rv;
+    b->cur ^= 1;
+    b->bus_cur = bi;
+    return SMX_OK;
+}
+
+extern "C" void *smx_bank_bus_dev(smx_bank *b) { return b ? b->d_bus[b->bus_cur] : nullptr; }
+
+extern "C" int smx_bank_sync(smx_bank *b)
+{
+    if (!b) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
+    return SMX_OK;
+}
+
+// linux/synth.c:180: (1.0 / 2^32) * (float)sum, product in double, result float
+static inline float bus_to_float(int32_t sum)
+{
+    return (float)((1.0 / 4294967296.0) * (double)(float)sum);
+}
+
+extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
+{
+    if (!b || n <= 0 || (uint32_t)n > b->bus_cap) { set_error("smx_bank_fetch: bad args"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    const int bi = b->bus_cur;
+    if (b->comm_pending[bi]) {
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
+        b->comm_pending[bi] = false;
+    }
+    SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (bus) memcpy(bus, b->h_bus, (size_t)n * 4);
+    if (vec) for (int i = 0; i < n; i++) vec[i] = bus_to_float(b->h_bus[i]);
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_run(smx_bank *b, float *vec, int32_t *bus, int n)
+{
+    int rv = smx_bank_run_async(b, n);
+    if (rv) return rv;
+    return smx_bank_fetch(b, vec, bus, n);
+}
+
+extern "C" int smx_bank_run_square(smx_bank *b, float *vec, int n)
+{
+    if (!b || n <= 0) { set_error("smx_bank_run_square: bad args"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    int rv = bank_ensure_bus(b, (uint32_t)n);
+    if (rv) return rv;
+    const int bi = b->bus_cur ^ 1;
+    if (b->comm_pending[bi]) {
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
+        b->comm_pending[bi] = false;
+    }
+    SMX_HIP(hipMemsetAsync(b->d_bus[bi], 0, (size_t)n * 4, b->stream));
+    rv = smx::launch_square_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1],
+                                 (uint32_t *)b->d_bus[bi], b->n_pad, (uint32_t)n, b->stream);
+    if (rv) return rv;
+    b->cur ^= 1;
+    b->bus_cur = bi;
+    SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    // linux/synth.c:194: (1.0 / 2^32) * (float)accu, accu unsigned
+    if (vec)
+        for (int i = 0; i < n; i++)
+            vec[i] = (float)((1.0 / 4294967296.0) * (double)(float)(uint32_t)b->h_bus[i]);
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_timer_start(smx_bank *b)
+{
+    if (!b) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipEventRecord(b->ev_t0, b->stream));
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_timer_stop(smx_bank *b, float *ms)
+{
+    if (!b || !ms) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipEventRecord(b->ev_t1, b->stream));
+    SMX_HIP(hipEventSynchronize(b->ev_t1));
+    SMX_HIP(hipEventElapsedTime(ms, b->ev_t0, b->ev_t1));
+    return SMX_OK;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------
+#define SMX_NCCL(expr)                                                         \
+    do {                                                                       \
+        ncclResult_t r_ = (expr);                                              \
+        if (r_ != ncclSuccess) {                                               \
+            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
+                      ncclGetErrorString(r_));                                 \
+            return SMX_E_COMM;                                                 \
+        }                                                                      \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == SMX_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+extern "C" int smx_comm_unique_id(uint8_t id[SMX_UNIQUE_ID_BYTES])
+{
+    ncclUniqueId u;
+    SMX_NCCL(ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_comm_init(smx_bank *b, int rank, int nranks,
+                                  const uint8_t id[SMX_UNIQUE_ID_BYTES])
+{
+    if (!b || nranks < 1 || rank < 0 || rank >= nranks) { set_error("smx_bank_comm_init: bad args"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    SMX_NCCL(ncclCommInitRank(&b->comm, nranks, u, rank));
+    SMX_HIP(hipStreamCreateWithFlags(&b->comm_stream, hipStreamNonBlocking));
+    b->rank = rank;
+    b->nranks = nranks;
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_allreduce_async(smx_bank *b, int n)
+{
+    if (!b || n <= 0 || (uint32_t)n > b->bus_cap) { set_error("smx_bank_allreduce_async: bad args"); return SMX_E_ARG; }
+    if (!b->comm) { set_error("smx_bank_allreduce_async: smx_bank_comm_init not called"); return SMX_E_STATE; }
+    SMX_HIP(hipSetDevice(b->device));
+    const int bi = b->bus_cur;
+    SMX_HIP(hipEventRecord(b->ev_kernel[bi], b->stream));
+    SMX_HIP(hipStreamWaitEvent(b->comm_stream, b->ev_kernel[bi], 0));
+    // integer sum: associative, so the result is the same bits in any order
+    SMX_NCCL(ncclAllReduce(b->d_bus[bi], b->d_bus[bi], (size_t)n, ncclInt32, ncclSum, b->comm,
+                           b->comm_stream));
+    SMX_HIP(hipEventRecord(b->ev_comm[bi], b->comm_stream));
+    b->comm_pending[bi] = true;
+    return SMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Linux drop-in: linux/synth.c:42-45, 145-165, 196-206
+// ---------------------------------------------------------------------------
+static smx_bank *g_dropin = nullptr;      // 64-voice scratch bank, JACK RT thread only
+static std::mutex g_dropin_mu;
+
+extern "C" int voice_alloc(struct synth *x)
+{
+    for (unsigned v = 0; v < 64; v++)
+        if (x->voice[v].note_inc == 0) return (int)v;
+    return 0;
+}
+
+extern "C" void synth_note_on(struct synth *x, int note)
+{
+    const int v = voice_alloc(x);
+    x->note2voice[note % 128] = v;
+    x->voice[v].note_inc = note_to_inc(note % 128);
+}
+
+extern "C" void synth_note_off(struct synth *x, int note)
+{
+    const int v = x->note2voice[note % 128];
+    x->note2voice[note % 128] = 0;
+    x->voice[v].note_inc = 0;
+}
+
+extern "C" void synth_init(struct synth *x) { memset(x, 0, sizeof(*x)); }
+
+extern "C" void synth_midi_event(struct synth *x, const uint8_t *msg, size_t size)
+{
+    if (size != 3) return;
+    if (msg[0] == 0x90) {                     // note on, channel 0 (linux/synth.c:246-256)
+        if (msg[2] == 0) synth_note_off(x, msg[1]);
+        else synth_note_on(x, msg[1]);
+    } else if (msg[0] == 0x80) {              // note off, channel 0 (:257-261)
+        synth_note_off(x, msg[1]);
+    }                                         // CC 23..31 on 0xB0: accepted, no action (:240-245)
+}
+
+extern "C" void synth_run(struct synth *x, float *vec, int n)
+{
+    if (n <= 0) return;
+    std::lock_guard<std::mutex> lock(g_dropin_mu);
+    if (!g_dropin) {
+        g_dropin = smx_bank_create(64, 0);
+        if (!g_dropin) SMX_ASSERT_OK(SMX_E_NOGPU, "synth_run: smx_bank_create");
+    }
+    uint32_t inc[64], state[64];
+    for (int v = 0; v < 64; v++) { inc[v] = x->voice[v].note_inc; state[v] = x->voice[v].note_state; }
+    SMX_ASSERT_OK(smx_bank_load(g_dropin, inc, state), "synth_run: load");
+    SMX_ASSERT_OK(smx_bank_run(g_dropin, vec, nullptr, n), "synth_run: run");
+    SMX_ASSERT_OK(smx_bank_read(g_dropin, nullptr, state), "synth_run: read");
+    for (int v = 0; v < 64; v++) x->voice[v].note_state = state[v];
+}
+
+// ---------------------------------------------------------------------------
+// carry-out PDM bank: stm32f103/mod_pdm.c
+// ---------------------------------------------------------------------------
+struct smx_pdm {
+    uint32_t n = 0, n_pad = 0;
+    int device = 0;
+    uint32_t *d_setpoint = nullptr, *d_accu = nullptr;
+    uint32_t *d_dither = nullptr; uint32_t dither_cap = 0;
+    uint32_t *d_bits = nullptr; size_t bits_cap = 0;     // bytes
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+};
+
+extern "C" uint32_t pdm_safe_setpoint(uint32_t setpoint) { return setpoint; }  // mod_pdm.c:101-107
+
+extern "C" smx_pdm *smx_pdm_create(uint32_t n_channels, int device)
+{
+    if (n_channels == 0) { set_error("smx_pdm_create: n_channels == 0"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("smx_pdm_create: no HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { set_error("smx_pdm_create: device %d of %d", device, ndev); return nullptr; }
+    smx_pdm *p = new smx_pdm();
+    p->n = n_channels;
+    p->n_pad = smx::round_up(n_channels, 1024);
+    p->device = device;
+    const size_t bytes = (size_t)p->n_pad * 4;
+    bool ok = hipSetDevice(device) == hipSuccess &&
+              hipMalloc((void **)&p->d_setpoint, bytes) == hipSuccess &&
+              hipMalloc((void **)&p->d_accu, bytes) == hipSuccess &&
+              hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&p->ev_t0) == hipSuccess && hipEventCreate(&p->ev_t1) == hipSuccess &&
+              hipMemsetAsync(p->d_setpoint, 0, bytes, p->stream) == hipSuccess &&
+              hipMemsetAsync(p->d_accu, 0, bytes, p->stream) == hipSuccess &&
+              hipStreamSynchronize(p->stream) == hipSuccess;
+    if (!ok) {
+        set_error("smx_pdm_create: HIP allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        smx_pdm_destroy(p);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void smx_pdm_destroy(smx_pdm *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->d_setpoint) (void)hipFree(p->d_setpoint);
+    if (p->d_accu) (void)hipFree(p->d_accu);
+    if (p->d_dither) (void)hipFree(p->d_dither);
+    if (p->d_bits) (void)hipFree(p->d_bits);
+    if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
+    if (p->ev_t1) (void)hipEventDestroy(p->ev_t1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+extern "C" int smx_pdm_load(smx_pdm *p, const uint32_t *setpoint, const uint32_t *accu)
+{
+    if (!p) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(p->device));
+    SMX_HIP(hipStreamSynchronize(p->stream));
+    if (setpoint) SMX_HIP(hipMemcpy(p->d_setpoint, setpoint, (size_t)p->n * 4, hipMemcpyHostToDevice));
+    if (accu) SMX_HIP(hipMemcpy(p->d_accu, accu, (size_t)p->n * 4, hipMemcpyHostToDevice));
+    return SMX_OK;
+}
+
+extern "C" int smx_pdm_read(smx_pdm *p, uint32_t *setpoint, uint32_t *accu)
+{
+    if (!p) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(p->device));
+    SMX_HIP(hipStreamSynchronize(p->stream));
+    if (setpoint) SMX_HIP(hipMemcpy(setpoint, p->d_setpoint, (size_t)p->n * 4, hipMemcpyDeviceToHost));
+    if (accu) SMX_HIP(hipMemcpy(accu, p->d_accu, (size_t)p->n * 4, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+// pdm_init, mod_pdm.c:320-326
+extern "C" int smx_pdm_init(smx_pdm *p)
+{
+    if (!p) return SMX_E_ARG;
+    std::vector<uint32_t> sp(p->n, pdm_safe_setpoint(0x40000000u)), ac(p->n, 0u);
+    sp[0] = 2000000000u;
+    return smx_pdm_load(p, sp.data(), ac.data());
+}
+
+// SETPOINT, mod_synth.c:104-111
+extern "C" int smx_pdm_set_setpoint(smx_pdm *p, uint32_t chan, uint32_t val)
+{
+    if (!p) return SMX_E_ARG;
+    if (chan >= p->n) { set_error("smx_pdm_set_setpoint: chan %u >= %u", chan, p->n); return SMX_E_RANGE; }
+    SMX_HIP(hipSetDevice(p->device));
+    const uint32_t v = pdm_safe_setpoint(val);
+    SMX_HIP(hipMemcpyAsync(p->d_setpoint + chan, &v, 4, hipMemcpyHostToDevice, p->stream));
+    SMX_HIP(hipStreamSynchronize(p->stream));
+    return SMX_OK;
+}
+
+static int pdm_ensure(smx_pdm *p, uint32_t n_ticks)
+{
+    const size_t need = (size_t)n_ticks * (p->n_pad / 8);
+    if (need > p->bits_cap) {
+        SMX_HIP(hipStreamSynchronize(p->stream));
+        if (p->d_bits) SMX_HIP(hipFree(p->d_bits));
+        p->d_bits = nullptr; p->bits_cap = 0;
+        SMX_HIP(hipMalloc((void **)&p->d_bits, need));
+        p->bits_cap = need;
+    }
+    if (n_ticks > p->dither_cap) {
+        SMX_HIP(hipStreamSynchronize(p->stream));
+        if (p->d_dither) SMX_HIP(hipFree(p->d_dither));
+        p->d_dither = nullptr; p->dither_cap = 0;
+        SMX_HIP(hipMalloc((void **)&p->d_dither, (size_t)n_ticks * 4));
+        p->dither_cap = n_ticks;
+    }
+    return SMX_OK;
+}
+
+extern "C" void *smx_pdm_dither_dev(smx_pdm *p, uint32_t n_ticks)
+{
+    if (!p || hipSetDevice(p->device) != hipSuccess || pdm_ensure(p, n_ticks) != SMX_OK) return nullptr;
+    return p->d_dither;
+}
+
+extern "C" void *smx_pdm_bits_dev(smx_pdm *p) { return p ? p->d_bits : nullptr; }
+
+extern "C" int smx_pdm_tick_n_async(smx_pdm *p, uint32_t n_ticks, int with_dither)
+{
+    if (!p) return SMX_E_ARG;
+    if (n_ticks == 0) return SMX_OK;
+    SMX_HIP(hipSetDevice(p->device));
+    int rv = pdm_ensure(p, n_ticks);
+    if (rv) return rv;
+    return smx::launch_pdm_bank(p->d_setpoint, p->d_accu, with_dither ? p->d_dither : nullptr,
+                                p->d_bits, p->n_pad, p->n, n_ticks, p->stream);
+}
+
+extern "C" int smx_pdm_sync(smx_pdm *p)
+{
+    if (!p) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(p->device));
+    SMX_HIP(hipStreamSynchronize(p->stream));
+    return SMX_OK;
+}
+
+extern "C" int smx_pdm_tick_n(smx_pdm *p, uint32_t n_ticks, const uint32_t *dither, uint32_t *bits)
+{
+    if (!p) return SMX_E_ARG;
+    if (n_ticks == 0) return SMX_OK;
+    SMX_HIP(hipSetDevice(p->device));
+    int rv = pdm_ensure(p, n_ticks);
+    if (rv) return rv;
+    if (dither)
+        SMX_HIP(hipMemcpyAsync(p->d_dither, dither, (size_t)n_ticks * 4, hipMemcpyHostToDevice, p->stream));
+    rv = smx_pdm_tick_n_async(p, n_ticks, dither != nullptr);
+    if (rv) return rv;
+    if (bits) {
+        const size_t words = (p->n + 31) / 32;
+        SMX_HIP(hipMemcpy2DAsync(bits, words * 4, p->d_bits, (size_t)p->n_pad / 8, words * 4, n_ticks,
+                                 hipMemcpyDeviceToHost, p->stream));
+    }
+    SMX_HIP(hipStreamSynchronize(p->stream));
+    return SMX_OK;
+}
+
+extern "C" int smx_pdm_timer_start(smx_pdm *p)
+{
+    if (!p) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(p->device));
+    SMX_HIP(hipEventRecord(p->ev_t0, p->stream));
+    return SMX_OK;
+}
+
+extern "C" int smx_pdm_timer_stop(smx_pdm *p, float *ms)
+{
+    if (!p || !ms) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(p->device));
+    SMX_HIP(hipEventRecord(p->ev_t1, p->stream));
+    SMX_HIP(hipEventSynchronize(p->ev_t1));
+    SMX_HIP(hipEventElapsedTime(ms, p->ev_t0, p->ev_t1));
+    return SMX_OK;
+}
+
+// mod_pdm.c:271-286: the reference's rrx register holds channel c at bit
+// 32-nb+c; shifted right by (32-nb-4) that is bit 4+c.
+extern "C" uint32_t smx_pdm_bsrr_word(uint32_t pulse_bits, uint32_t nb)
+{
+    if (nb == 0 || nb > 12) return 0;
+    const uint32_t mask = ((1u << nb) - 1) << 4;
+    const uint32_t set = (pulse_bits << 4) & mask;
+    const uint32_t clr = (~set) & mask;
+    return set | (clr << 16);
+}

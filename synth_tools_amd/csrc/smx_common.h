@@ -1,0 +1,52 @@
+// smx_common.h -- shared host-side plumbing for libsynth_mi355x.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include "../../include/synth_mi355x.h"
+
+namespace smx {
+
+void set_error(const char *fmt, ...);
+
+// Non-void ABI calls: record the message and return SMX_E_NOGPU.
+#define SMX_HIP(expr)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            smx::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,       \
+                           hipGetErrorString(e_));                             \
+            return SMX_E_NOGPU;                                                \
+        }                                                                      \
+    } while (0)
+
+// void reference-named calls: the reference's ASSERT convention
+// (linux/erl_tools_system.h:15,24-27): log and exit(1).
+#define SMX_ASSERT_OK(rv, what)                                                \
+    do {                                                                       \
+        if ((rv) != SMX_OK) {                                                  \
+            fprintf(stderr, "libsynth_mi355x: %s failed (%d): %s\n", what,     \
+                    (int)(rv), smx_last_error());                              \
+            exit(1);                                                           \
+        }                                                                      \
+    } while (0)
+
+static inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+// ---- kernel launchers (defined in the .hip files) --------------------------
+// Saw bank (saw_bank.hip).  n_pad is a multiple of 1024; bus must be zeroed.
+int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
+                    uint32_t *d_state_out, int32_t *d_bus, uint32_t n_pad,
+                    uint32_t nframes, hipStream_t stream);
+int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
+                       uint32_t *d_state_out, uint32_t *d_or_bus, uint32_t n_pad,
+                       uint32_t nframes, hipStream_t stream);
+// Carry-out PDM bank (pdm_bank.hip).  n_pad multiple of 1024; d_bits rows are n_pad/8 bytes.
+int launch_pdm_bank(const uint32_t *d_setpoint, uint32_t *d_accu,
+                    const uint32_t *d_dither /*nullable*/, uint32_t *d_bits,
+                    uint32_t n_pad, uint32_t n, uint32_t nticks, hipStream_t stream);
+
+}  // namespace smx

@@ -1,0 +1,159 @@
+"""GPU parity: the HIP saw bank (through the C-ABI) against the CPU oracle.
+Bar: bit-exact (integer bus, final phases, and the float vec, whose only
+rounding is int32->float32, linux/synth.c:180)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from synth_tools_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _check(smx, orc, inc, state, frames_list):
+    bank = smx.SawBank(len(inc))
+    bank.load(inc, state)
+    st = state.copy()
+    for nf in frames_list:
+        bus, vec = bank.run(nf)
+        obus, ovec = oracle.synth_run(orc, inc, st, nf)
+        assert np.array_equal(bus, obus), "bus differs at n=%d frames=%d" % (len(inc), nf)
+        assert np.array_equal(vec.view(np.uint32), ovec.view(np.uint32))
+    ginc, gst = bank.read()
+    assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+    bank.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1024, 1025, 4097])
+def test_small_banks_ragged(smx, orc, inc_table, n):
+    inc, state = synthetic.saw_bank(n, 0x5EED0000 + n, inc_table, active_fraction=0.7)
+    _check(smx, orc, inc, state, [1, 2, 3, 5, 17, 31, 32, 33, 63, 64, 65, 127, 128, 200])
+
+
+def test_c2_65536_voices(smx, orc, inc_table):
+    """BASELINE config 2: 65 536 saw voices, bit-exact vs the CPU loop."""
+    inc, state = synthetic.saw_bank(65536, 0x5EED0002, inc_table)
+    _check(smx, orc, inc, state, [64, 64, 1, 1024, 100])
+
+
+def test_vector_path_1m_voices(smx, orc, inc_table):
+    """>= 2^20 voices take the 4-voices-per-lane kernel; ragged count, off voices."""
+    n = (1 << 20) + 5
+    inc, state = synthetic.saw_bank(n, 0x5EED0005, inc_table, active_fraction=0.9)
+    _check(smx, orc, inc, state, [64, 7, 1, 130])
+
+
+def test_all_off_and_all_full_scale(smx, orc):
+    n = 2048
+    _check(smx, orc, np.zeros(n, np.uint32), np.arange(n, dtype=np.uint32) * 77, [64, 3])
+    # every voice near full scale: the 32-bit mix wraps many times (linux/synth.c:171 `int sum`)
+    _check(smx, orc, np.full(n, 1, np.uint32), np.full(n, 0x7FFFFFF0, np.uint32), [64])
+    _check(smx, orc, np.full(n, 0xFFFFFFFF, np.uint32), np.full(n, 0x80000000, np.uint32), [64, 64])
+
+
+def test_note_on_off_over_n_voices(smx, orc):
+    """Allocator semantics of linux/synth.c:145-165 over a 1000-voice bank, including
+    stealing voice 0 when full and stray note-offs."""
+    n = 100
+    bank = smx.SawBank(n)
+    n2v = np.zeros(128, np.int32)
+    inc = np.zeros(n, np.uint32)
+    st = np.zeros(n, np.uint32)
+    rng = np.random.default_rng(11)
+    for step in range(400):
+        note = int(rng.integers(0, 128))
+        if rng.random() < 0.75:
+            bank.note_on(note)
+            orc.orc_note_on(n2v, inc, n, note)
+        else:
+            bank.note_off(note)
+            orc.orc_note_off(n2v, inc, n, note)
+        if step % 25 == 0:
+            bus, _ = bank.run(64)
+            obus, _ = oracle.synth_run(orc, inc, st, 64)
+            assert np.array_equal(bus, obus)
+    ginc, gst = bank.read()
+    assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+    assert np.count_nonzero(inc) == n            # the bank did fill up: stealing was exercised
+    bank.close()
+
+
+def test_dropin_synth_run(smx, orc):
+    """The reference's own entry points on a caller-owned struct synth
+    (linux/synth.c:42-45), incl. the SURVEY A.2 chord known-answer."""
+    L = smx.lib()
+    kat = json.load(open(os.path.join(GOLD, "survey_known_answers.json")))
+    x = smx.Synth()
+    L.synth_init(C.byref(x))
+    for note in (69, 72, 76):
+        L.synth_note_on(C.byref(x), note)
+    vec = np.zeros(8, np.float32)
+    L.synth_run(C.byref(x), vec, 8)
+    assert ["%08x" % v for v in vec.view(np.uint32)] == kat["chord_69_72_76_first8_float_bits"]
+    assert x.voice[0].note_inc == kat["chord_voice0_after8"]["inc"]
+    assert x.voice[0].note_state == kat["chord_voice0_after8"]["state"]
+
+    g = np.load(os.path.join(GOLD, "synth_run_derived.npz"))
+    L.synth_init(C.byref(x))
+    vecs = []
+    for op, a in g["script"]:
+        if op == 0:
+            L.synth_midi_event(C.byref(x), np.array([0x90, a, 100], np.uint8), 3)
+        elif op == 1:
+            L.synth_midi_event(C.byref(x), np.array([0x80, a, 0], np.uint8), 3)
+        else:
+            v = np.zeros(int(a), np.float32)
+            L.synth_run(C.byref(x), v, int(a))
+            vecs.append(v)
+    assert np.array_equal(np.concatenate(vecs).view(np.uint32), g["vec"].view(np.uint32))
+    assert [x.voice[v].note_state for v in range(64)] == g["state"].tolist()
+    assert [x.voice[v].note_inc for v in range(64)] == g["inc"].tolist()
+
+
+def test_square_variant(smx, orc, inc_table):
+    """sum_tick_square, linux/synth.c:182-195."""
+    for n, frac in ((64, 0.3), (3000, 0.001), (3000, 0.0)):
+        inc, state = synthetic.saw_bank(n, 0x5EED0100 + n, inc_table, active_fraction=frac)
+        bank = smx.SawBank(n)
+        bank.load(inc, state)
+        st = state.copy()
+        for nf in (64, 1, 100):
+            got = bank.run_square(nf)
+            want = np.array([orc.orc_sum_tick_square(inc, st, n) for _ in range(nf)], np.float32)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(bank.read()[1], st)
+        bank.close()
+
+
+def test_full_size_properties_8m_voices(smx, orc, inc_table):
+    """BASELINE config 5 size (8 Mi voices) on one GPU, through size-independent
+    properties: (1) closed-form phases, state' = state + B*inc for active voices;
+    (2) shard linearity: the bus of the whole bank equals the wrapping sum of the buses
+    of its 8 contiguous shards (this is exactly the multi-GPU decomposition);
+    (3) one shard spot-checked against the oracle."""
+    n, shards, nf = 8 << 20, 8, 64
+    inc, state = synthetic.saw_bank(n, 0x5EED0005, inc_table, active_fraction=0.95)
+    bank = smx.SawBank(n)
+    bank.load(inc, state)
+    bus, _ = bank.run(nf)
+    _, gst = bank.read()
+    assert np.array_equal(gst, state + np.uint32(nf) * inc)
+    bank.close()
+    acc = np.zeros(nf, np.int64)
+    per = n // shards
+    for s in range(shards):
+        sb = smx.SawBank(per)
+        sb.load(inc[s * per:(s + 1) * per], state[s * per:(s + 1) * per])
+        b, _ = sb.run(nf)
+        acc += b
+        if s == 3:
+            st = state[s * per:(s + 1) * per].copy()
+            ob, _ = oracle.synth_run(orc, np.ascontiguousarray(inc[s * per:(s + 1) * per]), st, nf)
+            assert np.array_equal(b, ob)
+        sb.close()
+    assert np.array_equal((acc & 0xFFFFFFFF).astype(np.uint32), bus.view(np.uint32))
