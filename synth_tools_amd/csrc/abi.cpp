@@ -151,15 +151,20 @@ struct smx_bank {
     uint32_t *d_inc = nullptr;
     uint32_t *d_state[2] = {nullptr, nullptr};   // ping-pong (saw_bank.hip)
     int cur = 0;
-    int32_t *d_bus[2] = {nullptr, nullptr};      // double-buffered for the all-reduce
+    // three bus buffers in rotation: [cur] holds the last block (and may be feeding an
+    // all-reduce), [cur+1] was zeroed by the last launch for the next one, [cur+2] is
+    // the one the next launch will zero.
+    static constexpr int NBUS = 3;
+    int32_t *d_bus[NBUS] = {nullptr, nullptr, nullptr};
+    uint32_t bus_zeroed[NBUS] = {0, 0, 0};       // leading frames known to be zero
     int bus_cur = 0;
     uint32_t bus_cap = 0;
     int32_t *h_bus = nullptr;                    // pinned
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
-    hipEvent_t ev_kernel[2] = {nullptr, nullptr};   // kernel of bus[i] finished
-    hipEvent_t ev_comm[2] = {nullptr, nullptr};     // all-reduce of bus[i] finished
-    bool comm_pending[2] = {false, false};
+    hipEvent_t ev_kernel[NBUS] = {nullptr, nullptr, nullptr};   // kernel of bus[i] finished
+    hipEvent_t ev_comm[NBUS] = {nullptr, nullptr, nullptr};     // all-reduce of bus[i] finished
+    bool comm_pending[NBUS] = {false, false, false};
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int note2voice[128];
@@ -172,10 +177,13 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
     SMX_HIP(hipStreamSynchronize(b->stream));
     if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
     const uint32_t cap = smx::round_up(n < 4096 ? 4096 : n, 4096);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < smx_bank::NBUS; i++) {
         if (b->d_bus[i]) SMX_HIP(hipFree(b->d_bus[i]));
         b->d_bus[i] = nullptr;
         SMX_HIP(hipMalloc((void **)&b->d_bus[i], (size_t)cap * 4));
+        SMX_HIP(hipMemset(b->d_bus[i], 0, (size_t)cap * 4));
+        b->bus_zeroed[i] = cap;
+        b->comm_pending[i] = false;
     }
     if (b->h_bus) SMX_HIP(hipHostFree(b->h_bus));
     b->h_bus = nullptr;
@@ -211,7 +219,7 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
     if ((e = hipEventCreate(&b->ev_t0)) != hipSuccess) return fail("event", e);
     if ((e = hipEventCreate(&b->ev_t1)) != hipSuccess) return fail("event", e);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < smx_bank::NBUS; i++) {
         if ((e = hipEventCreateWithFlags(&b->ev_kernel[i], hipEventDisableTiming)) != hipSuccess) return fail("event", e);
         if ((e = hipEventCreateWithFlags(&b->ev_comm[i], hipEventDisableTiming)) != hipSuccess) return fail("event", e);
     }
@@ -234,8 +242,9 @@ extern "C" void smx_bank_destroy(smx_bank *b)
     if (b->comm_stream) (void)hipStreamSynchronize(b->comm_stream);
     if (b->comm) (void)ncclCommDestroy(b->comm);
     if (b->d_inc) (void)hipFree(b->d_inc);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 2; i++)
         if (b->d_state[i]) (void)hipFree(b->d_state[i]);
+    for (int i = 0; i < smx_bank::NBUS; i++) {
         if (b->d_bus[i]) (void)hipFree(b->d_bus[i]);
         if (b->ev_kernel[i]) (void)hipEventDestroy(b->ev_kernel[i]);
         if (b->ev_comm[i]) (void)hipEventDestroy(b->ev_comm[i]);
@@ -305,22 +314,48 @@ extern "C" int smx_bank_note_off(smx_bank *b, int note)
     return bank_set_inc(b, (uint32_t)v, 0);
 }
 
+// Wait (on the compute stream) until nothing in flight still uses bus buffer i.
+static int bank_bus_release(smx_bank *b, int i)
+{
+    if (b->comm_pending[i]) {
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[i], 0));
+        b->comm_pending[i] = false;
+    }
+    return SMX_OK;
+}
+
+// Rotate to the next bus buffer and make sure its first n frames are zero.
+static int bank_bus_advance(smx_bank *b, uint32_t n, int *bi_out, int *bnext_out)
+{
+    const int bi = (b->bus_cur + 1) % smx_bank::NBUS;
+    const int bnext = (bi + 1) % smx_bank::NBUS;
+    int rv = bank_bus_release(b, bi);
+    if (rv) return rv;
+    rv = bank_bus_release(b, bnext);      // the launch is about to zero it
+    if (rv) return rv;
+    if (b->bus_zeroed[bi] < n) {
+        SMX_HIP(hipMemsetAsync(b->d_bus[bi], 0, (size_t)n * 4, b->stream));
+        b->bus_zeroed[bi] = n;
+    }
+    *bi_out = bi;
+    *bnext_out = bnext;
+    return SMX_OK;
+}
+
 extern "C" int smx_bank_run_async(smx_bank *b, int n)
 {
     if (!b || n <= 0) { set_error("smx_bank_run_async: bad args"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
     int rv = bank_ensure_bus(b, (uint32_t)n);
     if (rv) return rv;
-    const int bi = b->bus_cur ^ 1;
-    // the buffer being recycled may still be feeding an all-reduce
-    if (b->comm_pending[bi]) {
-        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
-        b->comm_pending[bi] = false;
-    }
-    SMX_HIP(hipMemsetAsync(b->d_bus[bi], 0, (size_t)n * 4, b->stream));
-    rv = smx::launch_saw_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1], b->d_bus[bi],
-                              b->n_pad, (uint32_t)n, b->stream);
+    int bi, bnext;
+    rv = bank_bus_advance(b, (uint32_t)n, &bi, &bnext);
     if (rv) return rv;
+    rv = smx::launch_saw_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1], b->d_bus[bi],
+                              b->d_bus[bnext], b->n_pad, (uint32_t)n, b->stream);
+    if (rv) return rv;
+    b->bus_zeroed[bi] = 0;                 // now holds this block's sums
+    b->bus_zeroed[bnext] = (uint32_t)n;    // cleared by the launch
     b->cur ^= 1;
     b->bus_cur = bi;
     return SMX_OK;
@@ -372,12 +407,11 @@ extern "C" int smx_bank_run_square(smx_bank *b, float *vec, int n)
     SMX_HIP(hipSetDevice(b->device));
     int rv = bank_ensure_bus(b, (uint32_t)n);
     if (rv) return rv;
-    const int bi = b->bus_cur ^ 1;
-    if (b->comm_pending[bi]) {
-        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
-        b->comm_pending[bi] = false;
-    }
+    const int bi = (b->bus_cur + 1) % smx_bank::NBUS;
+    rv = bank_bus_release(b, bi);
+    if (rv) return rv;
     SMX_HIP(hipMemsetAsync(b->d_bus[bi], 0, (size_t)n * 4, b->stream));
+    b->bus_zeroed[bi] = 0;
     rv = smx::launch_square_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1],
                                  (uint32_t *)b->d_bus[bi], b->n_pad, (uint32_t)n, b->stream);
     if (rv) return rv;

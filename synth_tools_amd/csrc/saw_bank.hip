@@ -23,12 +23,30 @@
 
 namespace {
 
-template <int TC, int VW>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Streaming accesses: a bank larger than the caches is touched exactly once per
+// launch, so its lines are loaded/stored non-temporally (measured +7 % HBM rate).
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void stream_store(T v, T *p)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int TC, int VW, bool NT>
 __global__ __launch_bounds__(256)
 void saw_bank_kernel(const uint32_t *__restrict__ inc,
                      const uint32_t *__restrict__ st_in,
                      uint32_t *__restrict__ st_out,
                      int32_t *__restrict__ bus,
+                     int32_t *__restrict__ bus_next,   // zeroed here for the NEXT launch
                      uint32_t ngroups,      // n_pad / VW
                      uint32_t nframes)      // total frames of this block
 {
@@ -38,6 +56,10 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     const uint32_t t0 = blockIdx.y * 64u;   // >0 only when TC == 64
 
     for (uint32_t i = tid; i < TC * 65; i += 256) (&M[0][0])[i] = 0;
+    // the bus is accumulated with atomics, so it must start at zero: each launch
+    // clears the buffer its successor will use (saves a fill kernel per step)
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (uint32_t i = tid; i < nframes; i += 256) bus_next[i] = 0;
 
     int32_t acc[TC];
 #pragma unroll
@@ -46,23 +68,23 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     for (uint32_t g = blockIdx.x * 256u + tid; g < ngroups; g += gridDim.x * 256u) {
         uint32_t vi[VW], vs[VW];
         if constexpr (VW == 4) {
-            const uint4 a = reinterpret_cast<const uint4 *>(inc)[g];
-            const uint4 b = reinterpret_cast<const uint4 *>(st_in)[g];
+            const u32x4 a = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + g);
+            const u32x4 b = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + g);
             vi[0] = a.x; vi[1] = a.y; vi[2] = a.z; vi[3] = a.w;
             vs[0] = b.x; vs[1] = b.y; vs[2] = b.z; vs[3] = b.w;
         } else {
-            vi[0] = inc[g];
-            vs[0] = st_in[g];
+            vi[0] = stream_load<NT>(inc + g);
+            vs[0] = stream_load<NT>(st_in + g);
         }
         if (blockIdx.y == 0) {
             // final state in closed form; inc == 0 leaves the phase untouched
             if constexpr (VW == 4) {
-                uint4 o;
+                u32x4 o;
                 o.x = vs[0] + nframes * vi[0]; o.y = vs[1] + nframes * vi[1];
                 o.z = vs[2] + nframes * vi[2]; o.w = vs[3] + nframes * vi[3];
-                reinterpret_cast<uint4 *>(st_out)[g] = o;
+                stream_store<NT>(o, reinterpret_cast<u32x4 *>(st_out) + g);
             } else {
-                st_out[g] = vs[0] + nframes * vi[0];
+                stream_store<NT>(vs[0] + nframes * vi[0], st_out + g);
             }
         }
 #pragma unroll
@@ -133,34 +155,43 @@ void square_bank_kernel(const uint32_t *__restrict__ inc,
     }
 }
 
-template <int TC, int VW>
-int launch_tc(const uint32_t *inc, const uint32_t *si, uint32_t *so, int32_t *bus,
+// Grid: persistent workgroups, grid-stride over voices.  In the HBM-bound regime
+// (few frames per launch) 2 workgroups per CU stream fastest (measured: 768 x 256
+// threads = 6.2 TB/s vs 5.6 TB/s at 2048); the VALU-bound regime wants every SIMD full.
+static uint32_t grid_cap(uint32_t tc, uint32_t gy)
+{
+    static const char *env = getenv("SMX_SAW_GRID");      // tuning override
+    uint32_t cap = env ? (uint32_t)atoi(env) : (tc <= 16 ? 768u : 2048u);
+    cap = (cap + gy - 1) / gy;
+    return cap < 1 ? 1 : cap;
+}
+
+template <int TC, int VW, bool NT>
+int launch_tc(const uint32_t *inc, const uint32_t *si, uint32_t *so, int32_t *bus, int32_t *bus_next,
               uint32_t n_pad, uint32_t nframes, hipStream_t stream)
 {
     const uint32_t ngroups = n_pad / VW;
     uint32_t gx = (ngroups + 255) / 256;
     const uint32_t gy = (nframes + 63) / 64;
-    // persistent over voices: about 8 workgroups per CU over the whole grid
-    const uint32_t cap = (2048 + gy - 1) / gy;
+    const uint32_t cap = grid_cap(TC, gy);
     if (gx > cap) gx = cap;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((saw_bank_kernel<TC, VW>), dim3(gx, gy), dim3(256), 0, stream,
-                       inc, si, so, bus, ngroups, nframes);
+    hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT>), dim3(gx, gy), dim3(256), 0, stream,
+                       inc, si, so, bus, bus_next, ngroups, nframes);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
 
-template <int VW>
-int launch_vw(const uint32_t *inc, const uint32_t *si, uint32_t *so, int32_t *bus,
+template <int VW, bool NT>
+int launch_vw(const uint32_t *inc, const uint32_t *si, uint32_t *so, int32_t *bus, int32_t *bus_next,
               uint32_t n_pad, uint32_t nframes, hipStream_t stream)
 {
-    if (nframes > 32) return launch_tc<64, VW>(inc, si, so, bus, n_pad, nframes, stream);
-    if (nframes > 16) return launch_tc<32, VW>(inc, si, so, bus, n_pad, nframes, stream);
-    if (nframes > 8)  return launch_tc<16, VW>(inc, si, so, bus, n_pad, nframes, stream);
-    if (nframes > 4)  return launch_tc<8, VW>(inc, si, so, bus, n_pad, nframes, stream);
-    if (nframes > 2)  return launch_tc<4, VW>(inc, si, so, bus, n_pad, nframes, stream);
-    if (nframes > 1)  return launch_tc<2, VW>(inc, si, so, bus, n_pad, nframes, stream);
-    return launch_tc<1, VW>(inc, si, so, bus, n_pad, nframes, stream);
+    if (nframes > 32) return launch_tc<64, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
+    if (nframes > 16) return launch_tc<32, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
+    if (nframes > 8)  return launch_tc<16, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
+    if (nframes > 4)  return launch_tc<8, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
+    if (nframes > 2)  return launch_tc<4, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
+    if (nframes > 1)  return launch_tc<2, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
+    return launch_tc<1, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
 }
 
 }  // namespace
@@ -168,17 +199,21 @@ int launch_vw(const uint32_t *inc, const uint32_t *si, uint32_t *so, int32_t *bu
 namespace smx {
 
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
-                    uint32_t *d_state_out, int32_t *d_bus, uint32_t n_pad,
-                    uint32_t nframes, hipStream_t stream)
+                    uint32_t *d_state_out, int32_t *d_bus, int32_t *d_bus_next,
+                    uint32_t n_pad, uint32_t nframes, hipStream_t stream)
 {
     if (n_pad == 0 || (n_pad & 1023) || nframes == 0) {
         set_error("launch_saw_bank: n_pad=%u nframes=%u", n_pad, nframes);
         return SMX_E_ARG;
     }
-    // 4 voices per lane once there are enough voices to fill the chip that way
+    // 4 voices per lane once there are enough voices to fill the chip that way;
+    // non-temporal streaming once the bank (12 B/voice) cannot live in the 256 MiB
+    // Infinity Cache between launches anyway
+    if (n_pad >= (1u << 24))
+        return launch_vw<4, true>(d_inc, d_state_in, d_state_out, d_bus, d_bus_next, n_pad, nframes, stream);
     if (n_pad >= (1u << 20))
-        return launch_vw<4>(d_inc, d_state_in, d_state_out, d_bus, n_pad, nframes, stream);
-    return launch_vw<1>(d_inc, d_state_in, d_state_out, d_bus, n_pad, nframes, stream);
+        return launch_vw<4, false>(d_inc, d_state_in, d_state_out, d_bus, d_bus_next, n_pad, nframes, stream);
+    return launch_vw<1, false>(d_inc, d_state_in, d_state_out, d_bus, d_bus_next, n_pad, nframes, stream);
 }
 
 int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in,

@@ -37,10 +37,11 @@ void set_error(const char *fmt, ...);
 static inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 
 // ---- kernel launchers (defined in the .hip files) --------------------------
-// Saw bank (saw_bank.hip).  n_pad is a multiple of 1024; bus must be zeroed.
+// Saw bank (saw_bank.hip).  n_pad is a multiple of 1024; d_bus[0..nframes) must be zero
+// on entry; the launch zeroes d_bus_next[0..nframes) for its successor.
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
-                    uint32_t *d_state_out, int32_t *d_bus, uint32_t n_pad,
-                    uint32_t nframes, hipStream_t stream);
+                    uint32_t *d_state_out, int32_t *d_bus, int32_t *d_bus_next,
+                    uint32_t n_pad, uint32_t nframes, hipStream_t stream);
 int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
                        uint32_t *d_state_out, uint32_t *d_or_bus, uint32_t n_pad,
                        uint32_t nframes, hipStream_t stream);

@@ -157,3 +157,29 @@ def test_full_size_properties_8m_voices(smx, orc, inc_table):
             assert np.array_equal(b, ob)
         sb.close()
     assert np.array_equal((acc & 0xFFFFFFFF).astype(np.uint32), bus.view(np.uint32))
+
+
+def test_rccl_allreduce_path_single_rank(smx, orc, inc_table):
+    """The in-library RCCL bus sum (smx_bank_comm_init / allreduce_async / fetch) with a
+    1-rank communicator: exercises the second stream, the events and the double-buffered
+    bus exactly as the multi-GPU bench does; the sum over one rank is the identity."""
+    n = 70000
+    inc, state = synthetic.saw_bank(n, 0x5EED0777, inc_table)
+    bank = smx.SawBank(n)
+    bank.load(inc, state)
+    bank.comm_init(0, 1, smx.comm_unique_id())
+    st = state.copy()
+    for nf in (64, 1, 64, 64, 7):
+        bank.run_async(nf)
+        bank.allreduce_async(nf)
+        want, _ = oracle.synth_run(orc, inc, st, nf)
+    bus, vec = bank.fetch(7)
+    assert np.array_equal(bus, want)
+    # back-to-back steps without fetching in between (the bench's pattern)
+    for _ in range(50):
+        bank.run_async(64)
+        bank.allreduce_async(64)
+        want, wvec = oracle.synth_run(orc, inc, st, 64)
+    bus, vec = bank.fetch(64)
+    assert np.array_equal(bus, want) and np.array_equal(vec.view(np.uint32), wvec.view(np.uint32))
+    bank.close()
