@@ -158,6 +158,23 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
                     "ms_per_step": round(ms, 4), "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
                     "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     p.close()
+    # BASELINE config 4: 256 Ki poly voices (saw + 1-pole LPF + ADSR + stereo mix; build-defined)
+    n = 1 << 18
+    pb = sta.PolyBank(n)
+    pb.load(**synthetic.poly_bank(n, 0x5EED0004, tab))
+    for _ in range(3):
+        pb.run_async(64)
+    pb.sync()
+    pb.timer_start()
+    reps = 50
+    for _ in range(reps):
+        pb.run_async(64)
+    ms = pb.timer_stop() / reps
+    pb.close()
+    alg = 60.0 * n + 64 * 8
+    out.append({"workload": "c4: poly bank (saw+LPF+ADSR, stereo), %d voices, 64 frames/step" % n,
+                "value": round(n * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
+                "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     return out
 
 

@@ -151,6 +151,34 @@ int   smx_pdm_timer_stop(smx_pdm *p, float *ms);
  * word, for nb <= 12 channels on pins 4.. */
 uint32_t smx_pdm_bsrr_word(uint32_t pulse_bits, uint32_t nb);
 
+/* ======================================================================== */
+/* 4. Poly voice bank (BASELINE config 4): saw -> 1-pole LPF -> ADSR -> stereo */
+/*    BUILD-DEFINED EXTENSION: the reference has no filter/envelope (FIXME at  */
+/*    linux/synth.c:150-152); defined in DESIGN.md §3.4 / oracle orc_poly_run. */
+/* ======================================================================== */
+typedef struct smx_poly smx_poly;
+/* Host-side view of the per-voice arrays (each n_voices long). */
+struct smx_poly_arrays {
+    uint32_t *inc, *phase;           /* phasor as linux/synth.c:31-34; inc 0 == off   */
+    float    *y, *a;                 /* filter state and coefficient (0..1)            */
+    uint32_t *level, *stage;         /* envelope level, stage 0 idle 1 A 2 D 3 S 4 R   */
+    uint32_t *gate;                  /* 0/1, sampled at the start of every block       */
+    uint32_t *ar, *dr, *sl, *rr;     /* per-sample rates and sustain level (u32)       */
+    uint32_t *pan;                   /* pan_l | pan_r << 16, each 0..256               */
+};
+smx_poly *smx_poly_create(uint32_t n_voices, int device);
+void      smx_poly_destroy(smx_poly *p);
+/* NULL members are skipped. */
+int smx_poly_load(smx_poly *p, const struct smx_poly_arrays *a);
+int smx_poly_read(smx_poly *p, const struct smx_poly_arrays *a);
+/* n frames (any n; run in launches of <= 64).  vec_lr: host float[2n] interleaved L,R
+ * (bus * 2^-32 as linux/synth.c:180) or NULL; bus_lr: host int32[2n] or NULL. */
+int smx_poly_run(smx_poly *p, float *vec_lr, int32_t *bus_lr, int n);
+int smx_poly_run_async(smx_poly *p, int n);      /* n <= 64, bus stays on the device */
+int smx_poly_sync(smx_poly *p);
+int smx_poly_timer_start(smx_poly *p);
+int smx_poly_timer_stop(smx_poly *p, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

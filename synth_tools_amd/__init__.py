@@ -33,6 +33,14 @@ class Synth(C.Structure):            # linux/synth.c:35-38
     _fields_ = [("note2voice", C.c_int * 128), ("voice", Voice * 64)]
 
 
+POLY_FIELDS = ("inc", "phase", "y", "a", "level", "stage", "gate", "ar", "dr", "sl", "rr", "pan")
+POLY_FLOAT = ("y", "a")
+
+
+class PolyArrays(C.Structure):       # struct smx_poly_arrays
+    _fields_ = [(k, C.c_void_p) for k in POLY_FIELDS]
+
+
 # Every symbol include/synth_mi355x.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 ABI = [
@@ -79,6 +87,15 @@ ABI = [
     ("smx_pdm_timer_start", C.c_int, [_P]),
     ("smx_pdm_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("smx_pdm_bsrr_word", C.c_uint32, [C.c_uint32, C.c_uint32]),
+    ("smx_poly_create", _P, [C.c_uint32, C.c_int]),
+    ("smx_poly_destroy", None, [_P]),
+    ("smx_poly_load", C.c_int, [_P, C.POINTER(PolyArrays)]),
+    ("smx_poly_read", C.c_int, [_P, C.POINTER(PolyArrays)]),
+    ("smx_poly_run", C.c_int, [_P, _P, _P, C.c_int]),
+    ("smx_poly_run_async", C.c_int, [_P, C.c_int]),
+    ("smx_poly_sync", C.c_int, [_P]),
+    ("smx_poly_timer_start", C.c_int, [_P]),
+    ("smx_poly_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
 ]
 ABI_DATA = ["midi_tab"]
 
@@ -244,4 +261,61 @@ class PdmBank:
     def timer_stop(self):
         ms = C.c_float()
         _check(lib().smx_pdm_timer_stop(self._h, C.byref(ms)), "smx_pdm_timer_stop")
+        return ms.value
+
+
+class PolyBank:
+    """Poly voice bank: saw -> 1-pole LPF -> ADSR -> stereo int32 bus (build-defined
+    extension, BASELINE config 4; definition: oracle orc_poly_run / DESIGN.md)."""
+
+    def __init__(self, n_voices, device=0):
+        self._h = lib().smx_poly_create(n_voices, device)
+        if not self._h:
+            raise SmxError("smx_poly_create: " + lib().smx_last_error().decode())
+        self.n = n_voices
+
+    def close(self):
+        if self._h:
+            lib().smx_poly_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _arrays(self, d):
+        keep = {}
+        for k in POLY_FIELDS:
+            if k in d and d[k] is not None:
+                keep[k] = np.ascontiguousarray(d[k], np.float32 if k in POLY_FLOAT else np.uint32)
+                assert keep[k].shape == (self.n,)
+        return PolyArrays(**{k: v.ctypes.data for k, v in keep.items()}), keep
+
+    def load(self, **arrays):
+        st, keep = self._arrays(arrays)
+        _check(lib().smx_poly_load(self._h, C.byref(st)), "smx_poly_load")
+
+    def read(self, fields=POLY_FIELDS):
+        out = {k: np.empty(self.n, np.float32 if k in POLY_FLOAT else np.uint32) for k in fields}
+        st = PolyArrays(**{k: v.ctypes.data for k, v in out.items()})
+        _check(lib().smx_poly_read(self._h, C.byref(st)), "smx_poly_read")
+        return out
+
+    def run(self, n):
+        """-> (bus_lr int32[n,2], vec_lr float32[n,2])"""
+        vec = np.empty((n, 2), np.float32)
+        bus = np.empty((n, 2), np.int32)
+        _check(lib().smx_poly_run(self._h, _ptr(vec), _ptr(bus), n), "smx_poly_run")
+        return bus, vec
+
+    def run_async(self, n):
+        _check(lib().smx_poly_run_async(self._h, n), "smx_poly_run_async")
+
+    def sync(self):
+        _check(lib().smx_poly_sync(self._h), "smx_poly_sync")
+
+    def timer_start(self):
+        _check(lib().smx_poly_timer_start(self._h), "smx_poly_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _check(lib().smx_poly_timer_stop(self._h, C.byref(ms)), "smx_poly_timer_stop")
         return ms.value

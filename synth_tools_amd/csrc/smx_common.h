@@ -50,4 +50,13 @@ int launch_pdm_bank(const uint32_t *d_setpoint, uint32_t *d_accu,
                     const uint32_t *d_dither /*nullable*/, uint32_t *d_bits,
                     uint32_t n_pad, uint32_t n, uint32_t nticks, hipStream_t stream);
 
+// Poly voice bank (poly_bank.hip): device SoA arrays, n_pad entries each.
+struct PolyArrays {
+    uint32_t *inc, *phase;
+    float *y, *a;
+    uint32_t *level, *stage, *gate, *ar, *dr, *sl, *rr, *pan;
+};
+int launch_poly_bank(const PolyArrays &p, int32_t *d_bus_lr, uint32_t n_pad, uint32_t nframes,
+                     hipStream_t stream);
+
 }  // namespace smx

@@ -42,3 +42,22 @@ def pdm_bank(n, seed):
 
 def dither_stream(nticks, seed, mask):
     return (splitmix64(seed, nticks) & np.uint64(mask)).astype(np.uint32)
+
+
+def poly_bank(n, seed, inc_table, active_fraction=1.0):
+    """c4 distribution: saw bank + LPF coefficient uniform [0.01, 0.5], ADSR rates
+    log-uniform, sustain uniform, pan uniform, envelopes at rest, gates random."""
+    inc, phase = saw_bank(n, seed, inc_table, active_fraction)
+    r = splitmix64(seed ^ 0xC4C4C4C4, 6 * n).reshape(6, n)
+    u = lambda k: (r[k] >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    a = (0.01 + 0.49 * u(0)).astype(np.float32)
+    # attack 1 ms .. 1 s at 48 kHz: rate = 2^32 / samples
+    rate = lambda x: np.minimum(2.0 ** 32 / (48.0 * 10.0 ** (3.0 * x)), 2.0 ** 32 - 1).astype(np.uint64).astype(np.uint32)
+    ar, dr, rr = rate(u(1)), rate(u(2)), rate(u(3))
+    sl = (u(4) * (2.0 ** 32 - 1)).astype(np.uint64).astype(np.uint32)
+    pl = (u(5) * 256.0 + 0.5).astype(np.uint32)
+    pan = (pl | ((np.uint32(256) - pl) << np.uint32(16))).astype(np.uint32)
+    gate = ((r[0] >> np.uint64(7)) & np.uint64(1)).astype(np.uint32)
+    z = np.zeros(n, np.uint32)
+    return dict(inc=inc, phase=phase, y=np.zeros(n, np.float32), a=a, level=z.copy(), stage=z.copy(),
+                gate=gate, ar=ar, dr=dr, sl=sl, rr=rr, pan=pan)
