@@ -179,6 +179,46 @@ int smx_poly_sync(smx_poly *p);
 int smx_poly_timer_start(smx_poly *p);
 int smx_poly_timer_stop(smx_poly *p, float *ms);
 
+/* ======================================================================== */
+/* 5. Noise-shaped PWM bank: stm32f103/mod_pdm_pwm.c:76-160, pdm.h:10-77,    */
+/*    mod_controlrate.c:28-57                                                */
+/* ======================================================================== */
+typedef struct smx_pwm smx_pwm;
+/* order = number of integrators of the noise shaper, 1..4 (pdm1..pdm4_update,
+ * pdm.h:13,32,48,67); the firmware uses 2 (PDM_ORDER, mod_pdm_pwm.c:85).
+ * Defaults: CONTROL_DIV_LOG 12 (mod_pdm_pwm.c:76), out_shift 32-PDM_DIV_LOG = 24
+ * (mod_pdm_pwm.c:115, mod_synth.c:29). */
+smx_pwm *smx_pwm_create(uint32_t n_channels, int order, int device);
+void     smx_pwm_destroy(smx_pwm *p);
+int      smx_pwm_config(smx_pwm *p, uint32_t control_div_log, uint32_t out_shift);
+/* pdm_init, mod_pdm_pwm.c:147-160: setpoints 0x40000000, channel 0 2000000000,
+ * lines and integrators 0, control_div_count 0. */
+int smx_pwm_init(smx_pwm *p);
+/* SETPOINT, mod_synth.c:104-111: -2 if chan is out of range. */
+int smx_pwm_set_setpoint(smx_pwm *p, uint32_t chan, uint32_t val);
+/* struct channel (mod_pdm_pwm.c:89-93) as host arrays of n_channels; velocities
+ * are int32 stored in uint32.  NULL members are skipped. */
+struct smx_pwm_arrays {
+    uint32_t *setpoint;
+    uint32_t *pos0, *vel0;           /* line[0] */
+    uint32_t *pos1, *vel1;           /* line[1] */
+    uint32_t *s[4];                  /* pdm integrators s1..s4 (first `order` used) */
+};
+int smx_pwm_load(smx_pwm *p, const struct smx_pwm_arrays *a);
+int smx_pwm_read(smx_pwm *p, const struct smx_pwm_arrays *a);
+int smx_pwm_set_div_count(smx_pwm *p, uint32_t control_div_count);
+uint32_t smx_pwm_div_count(const smx_pwm *p);
+/* n_ticks of the ISR (mod_pdm_pwm.c:123-143).  dither: host uint32[n_ticks] or
+ * NULL (= 0), shared by all channels of a tick (the firmware masks its
+ * generator with 0x3FF, mod_pdm_pwm.c:127).  duty: host uint8[n_ticks *
+ * n_channels] tick-major (low 8 bits of the shaper output) or NULL. */
+int smx_pwm_tick_n(smx_pwm *p, uint32_t n_ticks, const uint32_t *dither, uint8_t *duty);
+int   smx_pwm_tick_n_async(smx_pwm *p, uint32_t n_ticks, int with_dither);
+void *smx_pwm_dither_dev(smx_pwm *p, uint32_t n_ticks);
+int   smx_pwm_sync(smx_pwm *p);
+int   smx_pwm_timer_start(smx_pwm *p);
+int   smx_pwm_timer_stop(smx_pwm *p, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ class PwmBank(C.Structure):
     _fields_ = [("n", C.c_uint32),
                 ("setpoint", C.c_void_p), ("pos0", C.c_void_p), ("vel0", C.c_void_p),
                 ("pos1", C.c_void_p), ("vel1", C.c_void_p),
-                ("s1", C.c_void_p), ("s2", C.c_void_p),
+                ("s", C.c_void_p * 4), ("order", C.c_uint32),
                 ("div_count", C.c_uint32), ("div_log", C.c_uint32), ("out_shift", C.c_uint32)]
 
 

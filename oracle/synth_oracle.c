@@ -242,9 +242,15 @@ void orc_pwm_bank_run(struct orc_pwm_bank *b, const uint32_t *dither,
         }
         for (uint32_t c = 0; c < b->n; c++) {         /* PDM_UPDATE_CHANNEL :108-116 */
             b->pos0[c] += (uint32_t)b->vel0[c];       /* glide :95-98 */
-            uint32_t s[2] = { b->s1[c], b->s2[c] };
-            uint32_t q = orc_pdm2_update(s, b->pos0[c], b->out_shift, d);
-            b->s1[c] = s[0]; b->s2[c] = s[1];
+            uint32_t s[4] = {0, 0, 0, 0}, q;
+            for (uint32_t k = 0; k < b->order; k++) s[k] = b->s[k][c];
+            switch (b->order) {                       /* PDM_UPDATE = pdm<ORDER>_update :87 */
+            case 1:  q = orc_pdm1_update(s, b->pos0[c], b->out_shift); break;   /* no dither input */
+            case 2:  q = orc_pdm2_update(s, b->pos0[c], b->out_shift, d); break;
+            case 3:  q = orc_pdm3_update(s, b->pos0[c], b->out_shift, d); break;
+            default: q = orc_pdm4_update(s, b->pos0[c], b->out_shift, d); break;
+            }
+            for (uint32_t k = 0; k < b->order; k++) b->s[k][c] = s[k];
             if (duty) duty[(size_t)t * b->n + c] = (uint8_t)q;
         }
         b->div_count = (b->div_count + 1) % div;

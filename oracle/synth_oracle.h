@@ -81,7 +81,8 @@ struct orc_pwm_bank {
     uint32_t *setpoint;
     uint32_t *pos0; int32_t *vel0;   /* line[0] */
     uint32_t *pos1; int32_t *vel1;   /* line[1] */
-    uint32_t *s1, *s2;               /* struct pdm2 */
+    uint32_t *s[4];                  /* struct pdm1..pdm4: s1..s<order> */
+    uint32_t order;                  /* PDM_ORDER = 2 in the firmware (mod_pdm_pwm.c:85) */
     uint32_t div_count;
     uint32_t div_log;                /* CONTROL_DIV_LOG = 12 */
     uint32_t out_shift;              /* 32 - PDM_DIV_LOG = 24 */

@@ -41,6 +41,10 @@ class PolyArrays(C.Structure):       # struct smx_poly_arrays
     _fields_ = [(k, C.c_void_p) for k in POLY_FIELDS]
 
 
+class PwmArrays(C.Structure):        # struct smx_pwm_arrays
+    _fields_ = [(k, C.c_void_p) for k in ("setpoint", "pos0", "vel0", "pos1", "vel1")] + [("s", C.c_void_p * 4)]
+
+
 # Every symbol include/synth_mi355x.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 ABI = [
@@ -96,6 +100,21 @@ ABI = [
     ("smx_poly_sync", C.c_int, [_P]),
     ("smx_poly_timer_start", C.c_int, [_P]),
     ("smx_poly_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("smx_pwm_create", _P, [C.c_uint32, C.c_int, C.c_int]),
+    ("smx_pwm_destroy", None, [_P]),
+    ("smx_pwm_config", C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    ("smx_pwm_init", C.c_int, [_P]),
+    ("smx_pwm_set_setpoint", C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    ("smx_pwm_load", C.c_int, [_P, C.POINTER(PwmArrays)]),
+    ("smx_pwm_read", C.c_int, [_P, C.POINTER(PwmArrays)]),
+    ("smx_pwm_set_div_count", C.c_int, [_P, C.c_uint32]),
+    ("smx_pwm_div_count", C.c_uint32, [_P]),
+    ("smx_pwm_tick_n", C.c_int, [_P, C.c_uint32, _P, _P]),
+    ("smx_pwm_tick_n_async", C.c_int, [_P, C.c_uint32, C.c_int]),
+    ("smx_pwm_dither_dev", _P, [_P, C.c_uint32]),
+    ("smx_pwm_sync", C.c_int, [_P]),
+    ("smx_pwm_timer_start", C.c_int, [_P]),
+    ("smx_pwm_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
 ]
 ABI_DATA = ["midi_tab"]
 
@@ -318,4 +337,79 @@ class PolyBank:
     def timer_stop(self):
         ms = C.c_float()
         _check(lib().smx_poly_timer_stop(self._h, C.byref(ms)), "smx_poly_timer_stop")
+        return ms.value
+
+
+PWM_FIELDS = ("setpoint", "pos0", "vel0", "pos1", "vel1", "s1", "s2", "s3", "s4")
+
+
+class PwmBank:
+    """N-channel noise-shaped PWM bank with control-rate glide
+    (stm32f103/mod_pdm_pwm.c, pdm.h, mod_controlrate.c)."""
+
+    def __init__(self, n_channels, order=2, device=0, control_div_log=12, out_shift=24):
+        self._h = lib().smx_pwm_create(n_channels, order, device)
+        if not self._h:
+            raise SmxError("smx_pwm_create: " + lib().smx_last_error().decode())
+        self.n, self.order = n_channels, order
+        _check(lib().smx_pwm_config(self._h, control_div_log, out_shift), "smx_pwm_config")
+
+    def close(self):
+        if self._h:
+            lib().smx_pwm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _struct(self, d):
+        s = (C.c_void_p * 4)(*[d["s%d" % k].ctypes.data if d.get("s%d" % k) is not None else None
+                               for k in (1, 2, 3, 4)])
+        return PwmArrays(s=s, **{k: (d[k].ctypes.data if d.get(k) is not None else None)
+                                 for k in ("setpoint", "pos0", "vel0", "pos1", "vel1")})
+
+    def init(self):
+        _check(lib().smx_pwm_init(self._h), "smx_pwm_init")
+
+    def set_setpoint(self, chan, val):
+        return lib().smx_pwm_set_setpoint(self._h, chan, val)
+
+    def load(self, **arrays):
+        keep = {k: np.ascontiguousarray(v).view(np.uint32) for k, v in arrays.items() if v is not None}
+        for v in keep.values():
+            assert v.shape == (self.n,)
+        st = self._struct(keep)
+        _check(lib().smx_pwm_load(self._h, C.byref(st)), "smx_pwm_load")
+
+    def read(self):
+        out = {k: np.empty(self.n, np.uint32) for k in PWM_FIELDS[:5 + self.order]}
+        st = self._struct(out)
+        _check(lib().smx_pwm_read(self._h, C.byref(st)), "smx_pwm_read")
+        return out
+
+    @property
+    def div_count(self):
+        return lib().smx_pwm_div_count(self._h)
+
+    @div_count.setter
+    def div_count(self, c):
+        _check(lib().smx_pwm_set_div_count(self._h, c), "smx_pwm_set_div_count")
+
+    def tick_n(self, n_ticks, dither=None, want_duty=True):
+        d = None if dither is None else np.ascontiguousarray(dither, np.uint32)
+        duty = np.empty((n_ticks, self.n), np.uint8) if want_duty else None
+        _check(lib().smx_pwm_tick_n(self._h, n_ticks, _ptr(d), _ptr(duty)), "smx_pwm_tick_n")
+        return duty
+
+    def tick_n_async(self, n_ticks, with_dither=False):
+        _check(lib().smx_pwm_tick_n_async(self._h, n_ticks, int(with_dither)), "smx_pwm_tick_n_async")
+
+    def sync(self):
+        _check(lib().smx_pwm_sync(self._h), "smx_pwm_sync")
+
+    def timer_start(self):
+        _check(lib().smx_pwm_timer_start(self._h), "smx_pwm_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _check(lib().smx_pwm_timer_stop(self._h, C.byref(ms)), "smx_pwm_timer_stop")
         return ms.value

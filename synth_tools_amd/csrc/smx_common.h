@@ -59,4 +59,13 @@ struct PolyArrays {
 int launch_poly_bank(const PolyArrays &p, int32_t *d_bus_lr, uint32_t n_pad, uint32_t nframes,
                      hipStream_t stream);
 
+// Noise-shaped PWM bank (pwm_bank.hip): device SoA arrays, n_pad entries each.
+struct PwmArrays {
+    uint32_t *setpoint, *pos0, *vel0, *pos1, *vel1;
+    uint32_t *s[4];                     // integrators s1..sORDER
+};
+int launch_pwm_bank(const PwmArrays &p, int order, const uint32_t *d_dither, uint8_t *d_duty,
+                    uint32_t n_pad, uint32_t nticks, uint32_t div_count, uint32_t div_log,
+                    uint32_t out_shift, hipStream_t stream);
+
 }  // namespace smx

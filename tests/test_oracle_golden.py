@@ -241,14 +241,15 @@ def test_pdm_h_live_against_real_header(orc):
 
 
 # ---- mod_pdm_pwm.c / mod_controlrate.c / pmeas.h / cproc.h: restatement checks --
-def _pwm_bank(n, setpoint, div_log=12):
+def _pwm_bank(n, setpoint, div_log=12, order=2):
     import ctypes as C
-    arrs = {k: np.zeros(n, np.uint32) for k in ("setpoint", "pos0", "pos1", "s1", "s2")}
+    arrs = {k: np.zeros(n, np.uint32) for k in ("setpoint", "pos0", "pos1", "s1", "s2", "s3", "s4")}
     arrs["vel0"] = np.zeros(n, np.int32)
     arrs["vel1"] = np.zeros(n, np.int32)
     arrs["setpoint"][:] = setpoint
-    b = oracle.PwmBank(n=n, div_count=0, div_log=div_log, out_shift=24,
-                       **{k: v.ctypes.data for k, v in arrs.items()})
+    b = oracle.PwmBank(n=n, order=order, div_count=0, div_log=div_log, out_shift=24,
+                       s=(C.c_void_p * 4)(*[arrs["s%d" % k].ctypes.data for k in (1, 2, 3, 4)]),
+                       **{k: arrs[k].ctypes.data for k in ("setpoint", "pos0", "vel0", "pos1", "vel1")})
     return b, arrs
 
 
