@@ -219,6 +219,39 @@ int   smx_pwm_sync(smx_pwm *p);
 int   smx_pwm_timer_start(smx_pwm *p);
 int   smx_pwm_timer_stop(smx_pwm *p, float *ms);
 
+/* ======================================================================== */
+/* 6. Oscillator bank: stm32f103/mod_pdm.c:159-175 (pwm_update + hard sync), */
+/*    mod_osc.c:47-103 (osc ISR, sub-osc), pmeas.h:10-108 (period measurement)*/
+/* ======================================================================== */
+typedef struct smx_osc smx_osc;
+/* osc_init (mod_osc.c:82-103): log_max 26, everything else 0; pwm_phase 0,
+ * pwm_speed 256*13 (mod_pdm.c:160-161). */
+smx_osc *smx_osc_create(uint32_t n_oscillators, int device);
+void     smx_osc_destroy(smx_osc *o);
+/* MEASURE with one argument sets log_max (mod_synth.c:112-117). 1..31. */
+int smx_osc_set_log_max(smx_osc *o, uint32_t log_max);
+int smx_osc_load_pwm(smx_osc *o, const uint32_t *phase, const uint32_t *speed);
+int smx_osc_read_pwm(smx_osc *o, uint32_t *phase, uint32_t *speed);
+/* n_ticks of pwm_update (mod_pdm.c:167-175).  sync_bits: host
+ * uint32[n_ticks * ceil(n/32)] or NULL; a set bit (oscillator c -> bit c&31 of
+ * word c>>5 of row t) applies OSC_HARD_SYNC before tick t.  duty: host
+ * uint8[n_ticks * n] tick-major or NULL. */
+int smx_osc_tick_n(smx_osc *o, uint32_t n_ticks, const uint32_t *sync_bits, uint8_t *duty);
+/* n_events slots of the osc ISR (mod_osc.c:47-74): oscillator c takes slot e with
+ * cycle-counter timestamp cc[e*n + c] iff its valid bit is set (same layout;
+ * NULL = every oscillator takes every slot): sub-osc toggle + pmeas_update. */
+int smx_osc_events(smx_osc *o, uint32_t n_events, const uint32_t *cc, const uint32_t *valid_bits);
+/* struct pmeas_state as host arrays of n (NULL members skipped). */
+struct smx_pmeas_arrays {
+    uint32_t *write;                 /* low bit points at the current measurement */
+    uint32_t *avg0, *avg1;           /* meas[0..1].avg, (32-log_max) fractional bits */
+    uint32_t *num0, *num1;           /* meas[0..1].num */
+    uint32_t *num, *accu, *last_cc;  /* ISR-side state */
+    uint32_t *sub;                   /* sub-oscillator output bit (GPIOB pin 10) */
+};
+int smx_osc_load_pmeas(smx_osc *o, const struct smx_pmeas_arrays *a);
+int smx_osc_read_pmeas(smx_osc *o, const struct smx_pmeas_arrays *a);
+
 #ifdef __cplusplus
 }
 #endif

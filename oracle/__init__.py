@@ -70,6 +70,8 @@ def load():
     lib.orc_pwm_bank_run.argtypes = [C.POINTER(PwmBank), C.c_void_p, C.c_uint32, C.c_void_p]
     lib.orc_pmeas_update.argtypes = [C.POINTER(Pmeas), C.c_uint32]
     lib.orc_osc_event.argtypes = [C.POINTER(Pmeas), C.c_uint32]
+    lib.orc_pwmosc_run.argtypes = [_u32p, _u32p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.orc_osc_bank_events.argtypes = [C.POINTER(Pmeas), C.c_uint32, _u32p, C.c_void_p, C.c_uint32]
     lib.orc_acc_update.argtypes = [_u32p, C.c_uint32]
     lib.orc_edge_update.argtypes = [_u32p, _u32p, C.c_uint32]
     lib.orc_poly_run.argtypes = [C.POINTER(PolyBank), _i32p, C.c_int]

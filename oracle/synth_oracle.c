@@ -292,6 +292,27 @@ void orc_osc_event(struct orc_pmeas *p, uint32_t cc) {
     orc_pmeas_update(p, cc);
 }
 
+void orc_pwmosc_run(uint32_t *phase, const uint32_t *speed, uint32_t n,
+                    const uint32_t *sync_bits, uint32_t nticks, uint8_t *duty) {
+    uint32_t words = (n + 31) >> 5;
+    for (uint32_t t = 0; t < nticks; t++)
+        for (uint32_t c = 0; c < n; c++) {
+            if (sync_bits && ((sync_bits[(size_t)t * words + (c >> 5)] >> (c & 31)) & 1))
+                phase[c] = 0;                                  /* OSC_HARD_SYNC */
+            uint32_t d = orc_pwm_update(&phase[c], speed[c]);
+            if (duty) duty[(size_t)t * n + c] = (uint8_t)d;
+        }
+}
+
+void orc_osc_bank_events(struct orc_pmeas *p, uint32_t n, const uint32_t *cc,
+                         const uint32_t *valid_bits, uint32_t nevents) {
+    uint32_t words = (n + 31) >> 5;
+    for (uint32_t e = 0; e < nevents; e++)
+        for (uint32_t c = 0; c < n; c++)
+            if (!valid_bits || ((valid_bits[(size_t)e * words + (c >> 5)] >> (c & 31)) & 1))
+                orc_osc_event(&p[c], cc[(size_t)e * n + c]);
+}
+
 /* ======================================================================== */
 /* generic/cproc.h                                                          */
 /* ======================================================================== */

@@ -100,6 +100,17 @@ struct orc_pmeas {
 void orc_pmeas_update(struct orc_pmeas *p, uint32_t cc);     /* pmeas.h:64-100 */
 void orc_osc_event(struct orc_pmeas *p, uint32_t cc);        /* mod_osc.c:47-74 */
 
+/* Bank forms (lane-per-oscillator restatement targets).
+ * Wavetable/PWM phase bank: per tick, a set sync bit (channel c -> bit c&31 of word
+ * c>>5 of row t; NULL = never) applies OSC_HARD_SYNC (mod_pdm.c:159, mod_osc.c:60-62)
+ * before that tick's pwm_update (mod_pdm.c:167-175).  duty tick-major uint8. */
+void orc_pwmosc_run(uint32_t *phase, const uint32_t *speed, uint32_t n,
+                    const uint32_t *sync_bits, uint32_t nticks, uint8_t *duty);
+/* Event bank: E event slots; oscillator c takes slot e (timestamp cc[e*n+c]) iff its
+ * valid bit is set (same bit layout; NULL = all valid).  mod_osc.c:47-74. */
+void orc_osc_bank_events(struct orc_pmeas *p, uint32_t n, const uint32_t *cc,
+                         const uint32_t *valid_bits, uint32_t nevents);
+
 /* ---- generic/cproc.h ---------------------------------------------------- */
 void orc_acc_update(uint32_t *out, uint32_t in);                     /* :142-144 */
 void orc_edge_update(uint32_t *out, uint32_t *last, uint32_t in);    /* :152-155 */

@@ -41,6 +41,13 @@ class PolyArrays(C.Structure):       # struct smx_poly_arrays
     _fields_ = [(k, C.c_void_p) for k in POLY_FIELDS]
 
 
+PMEAS_FIELDS = ("write", "avg0", "avg1", "num0", "num1", "num", "accu", "last_cc", "sub")
+
+
+class PmeasArrays(C.Structure):      # struct smx_pmeas_arrays
+    _fields_ = [(k, C.c_void_p) for k in PMEAS_FIELDS]
+
+
 class PwmArrays(C.Structure):        # struct smx_pwm_arrays
     _fields_ = [(k, C.c_void_p) for k in ("setpoint", "pos0", "vel0", "pos1", "vel1")] + [("s", C.c_void_p * 4)]
 
@@ -115,6 +122,15 @@ ABI = [
     ("smx_pwm_sync", C.c_int, [_P]),
     ("smx_pwm_timer_start", C.c_int, [_P]),
     ("smx_pwm_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("smx_osc_create", _P, [C.c_uint32, C.c_int]),
+    ("smx_osc_destroy", None, [_P]),
+    ("smx_osc_set_log_max", C.c_int, [_P, C.c_uint32]),
+    ("smx_osc_load_pwm", C.c_int, [_P, _P, _P]),
+    ("smx_osc_read_pwm", C.c_int, [_P, _P, _P]),
+    ("smx_osc_tick_n", C.c_int, [_P, C.c_uint32, _P, _P]),
+    ("smx_osc_events", C.c_int, [_P, C.c_uint32, _P, _P]),
+    ("smx_osc_load_pmeas", C.c_int, [_P, C.POINTER(PmeasArrays)]),
+    ("smx_osc_read_pmeas", C.c_int, [_P, C.POINTER(PmeasArrays)]),
 ]
 ABI_DATA = ["midi_tab"]
 
@@ -413,3 +429,61 @@ class PwmBank:
         ms = C.c_float()
         _check(lib().smx_pwm_timer_stop(self._h, C.byref(ms)), "smx_pwm_timer_stop")
         return ms.value
+
+
+class OscBank:
+    """Oscillator bank: hard-synced PWM phase accumulators (mod_pdm.c:159-175) and the
+    osc event ISR with period measurement (mod_osc.c:47-74, pmeas.h:64-100)."""
+
+    def __init__(self, n, device=0):
+        self._h = lib().smx_osc_create(n, device)
+        if not self._h:
+            raise SmxError("smx_osc_create: " + lib().smx_last_error().decode())
+        self.n = n
+        self.words = (n + 31) // 32
+
+    def close(self):
+        if self._h:
+            lib().smx_osc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_log_max(self, log_max):
+        return lib().smx_osc_set_log_max(self._h, log_max)
+
+    def load_pwm(self, phase=None, speed=None):
+        phase = None if phase is None else np.ascontiguousarray(phase, np.uint32)
+        speed = None if speed is None else np.ascontiguousarray(speed, np.uint32)
+        _check(lib().smx_osc_load_pwm(self._h, _ptr(phase), _ptr(speed)), "smx_osc_load_pwm")
+
+    def read_pwm(self):
+        ph = np.empty(self.n, np.uint32)
+        sp = np.empty(self.n, np.uint32)
+        _check(lib().smx_osc_read_pwm(self._h, _ptr(ph), _ptr(sp)), "smx_osc_read_pwm")
+        return ph, sp
+
+    def tick_n(self, n_ticks, sync_bits=None, want_duty=True):
+        sb = None if sync_bits is None else np.ascontiguousarray(sync_bits, np.uint32)
+        assert sb is None or sb.size == n_ticks * self.words
+        duty = np.empty((n_ticks, self.n), np.uint8) if want_duty else None
+        _check(lib().smx_osc_tick_n(self._h, n_ticks, _ptr(sb), _ptr(duty)), "smx_osc_tick_n")
+        return duty
+
+    def events(self, cc, valid_bits=None):
+        cc = np.ascontiguousarray(cc, np.uint32)
+        ne = cc.size // self.n
+        vb = None if valid_bits is None else np.ascontiguousarray(valid_bits, np.uint32)
+        assert cc.size == ne * self.n and (vb is None or vb.size == ne * self.words)
+        _check(lib().smx_osc_events(self._h, ne, _ptr(cc), _ptr(vb)), "smx_osc_events")
+
+    def load_pmeas(self, **arrays):
+        keep = {k: np.ascontiguousarray(v, np.uint32) for k, v in arrays.items()}
+        st = PmeasArrays(**{k: v.ctypes.data for k, v in keep.items()})
+        _check(lib().smx_osc_load_pmeas(self._h, C.byref(st)), "smx_osc_load_pmeas")
+
+    def read_pmeas(self):
+        out = {k: np.empty(self.n, np.uint32) for k in PMEAS_FIELDS}
+        st = PmeasArrays(**{k: v.ctypes.data for k, v in out.items()})
+        _check(lib().smx_osc_read_pmeas(self._h, C.byref(st)), "smx_osc_read_pmeas")
+        return out

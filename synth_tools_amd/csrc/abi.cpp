@@ -1108,3 +1108,183 @@ extern "C" int smx_pwm_timer_stop(smx_pwm *p, float *ms)
     SMX_HIP(hipEventElapsedTime(ms, p->ev_t0, p->ev_t1));
     return SMX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// oscillator bank: mod_pdm.c pwm_update + hard sync, mod_osc.c ISR, pmeas.h
+// ---------------------------------------------------------------------------
+struct smx_osc {
+    uint32_t n = 0, n_pad = 0, log_max = 26;
+    int device = 0;
+    uint32_t *d_phase = nullptr, *d_speed = nullptr;
+    smx::PmeasArrays pm{};
+    void *d_tmp = nullptr; size_t tmp_cap = 0;      // sync/valid bits or timestamps
+    void *d_tmp2 = nullptr; size_t tmp2_cap = 0;
+    uint8_t *d_duty = nullptr; size_t duty_cap = 0;
+    hipStream_t stream = nullptr;
+};
+
+static void pmeas_slots(smx::PmeasArrays &d, void **slots[9])
+{
+    slots[0] = (void **)&d.write; slots[1] = (void **)&d.avg0; slots[2] = (void **)&d.avg1;
+    slots[3] = (void **)&d.num0;  slots[4] = (void **)&d.num1; slots[5] = (void **)&d.num;
+    slots[6] = (void **)&d.accu;  slots[7] = (void **)&d.last_cc; slots[8] = (void **)&d.sub;
+}
+
+static int dev_reserve(void **ptr, size_t *cap, size_t need, hipStream_t stream)
+{
+    if (need <= *cap) return SMX_OK;
+    SMX_HIP(hipStreamSynchronize(stream));
+    if (*ptr) SMX_HIP(hipFree(*ptr));
+    *ptr = nullptr; *cap = 0;
+    SMX_HIP(hipMalloc(ptr, need));
+    *cap = need;
+    return SMX_OK;
+}
+
+extern "C" smx_osc *smx_osc_create(uint32_t n, int device)
+{
+    if (n == 0) { set_error("smx_osc_create: n == 0"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("smx_osc_create: no HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { set_error("smx_osc_create: device %d of %d", device, ndev); return nullptr; }
+    smx_osc *o = new smx_osc();
+    o->n = n;
+    o->n_pad = smx::round_up(n, 1024);
+    o->device = device;
+    const size_t bytes = (size_t)o->n_pad * 4;
+    void **slots[9];
+    pmeas_slots(o->pm, slots);
+    bool ok = hipSetDevice(device) == hipSuccess &&
+              hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void **)&o->d_phase, bytes) == hipSuccess &&
+              hipMalloc((void **)&o->d_speed, bytes) == hipSuccess &&
+              hipMemsetAsync(o->d_phase, 0, bytes, o->stream) == hipSuccess;
+    for (int i = 0; ok && i < 9; i++)
+        ok = hipMalloc(slots[i], bytes) == hipSuccess && hipMemsetAsync(*slots[i], 0, bytes, o->stream) == hipSuccess;
+    if (ok) {
+        std::vector<uint32_t> sp(o->n_pad, 256u * 13u);          // pwm_speed, mod_pdm.c:161
+        ok = hipMemcpyAsync(o->d_speed, sp.data(), bytes, hipMemcpyHostToDevice, o->stream) == hipSuccess &&
+             hipStreamSynchronize(o->stream) == hipSuccess;
+    }
+    if (!ok) {
+        set_error("smx_osc_create: HIP allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        smx_osc_destroy(o);
+        return nullptr;
+    }
+    return o;
+}
+
+extern "C" void smx_osc_destroy(smx_osc *o)
+{
+    if (!o) return;
+    (void)hipSetDevice(o->device);
+    if (o->stream) (void)hipStreamSynchronize(o->stream);
+    void **slots[9];
+    pmeas_slots(o->pm, slots);
+    for (int i = 0; i < 9; i++)
+        if (*slots[i]) (void)hipFree(*slots[i]);
+    if (o->d_phase) (void)hipFree(o->d_phase);
+    if (o->d_speed) (void)hipFree(o->d_speed);
+    if (o->d_tmp) (void)hipFree(o->d_tmp);
+    if (o->d_tmp2) (void)hipFree(o->d_tmp2);
+    if (o->d_duty) (void)hipFree(o->d_duty);
+    if (o->stream) (void)hipStreamDestroy(o->stream);
+    delete o;
+}
+
+extern "C" int smx_osc_set_log_max(smx_osc *o, uint32_t log_max)
+{
+    if (!o || log_max == 0 || log_max > 31) { set_error("smx_osc_set_log_max: %u (1..31)", log_max); return SMX_E_ARG; }
+    o->log_max = log_max;
+    return SMX_OK;
+}
+
+extern "C" int smx_osc_load_pwm(smx_osc *o, const uint32_t *phase, const uint32_t *speed)
+{
+    if (!o) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(o->device));
+    SMX_HIP(hipStreamSynchronize(o->stream));
+    if (phase) SMX_HIP(hipMemcpy(o->d_phase, phase, (size_t)o->n * 4, hipMemcpyHostToDevice));
+    if (speed) SMX_HIP(hipMemcpy(o->d_speed, speed, (size_t)o->n * 4, hipMemcpyHostToDevice));
+    return SMX_OK;
+}
+
+extern "C" int smx_osc_read_pwm(smx_osc *o, uint32_t *phase, uint32_t *speed)
+{
+    if (!o) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(o->device));
+    SMX_HIP(hipStreamSynchronize(o->stream));
+    if (phase) SMX_HIP(hipMemcpy(phase, o->d_phase, (size_t)o->n * 4, hipMemcpyDeviceToHost));
+    if (speed) SMX_HIP(hipMemcpy(speed, o->d_speed, (size_t)o->n * 4, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+extern "C" int smx_osc_tick_n(smx_osc *o, uint32_t n_ticks, const uint32_t *sync_bits, uint8_t *duty)
+{
+    if (!o) return SMX_E_ARG;
+    if (n_ticks == 0) return SMX_OK;
+    SMX_HIP(hipSetDevice(o->device));
+    int rv = dev_reserve((void **)&o->d_duty, &o->duty_cap, (size_t)n_ticks * o->n_pad, o->stream);
+    if (rv) return rv;
+    const uint32_t *d_sync = nullptr;
+    if (sync_bits) {
+        const size_t row = (size_t)o->n_pad / 8, words = (o->n + 31) / 32;
+        rv = dev_reserve(&o->d_tmp, &o->tmp_cap, (size_t)n_ticks * row, o->stream);
+        if (rv) return rv;
+        SMX_HIP(hipMemsetAsync(o->d_tmp, 0, (size_t)n_ticks * row, o->stream));
+        SMX_HIP(hipMemcpy2DAsync(o->d_tmp, row, sync_bits, words * 4, words * 4, n_ticks,
+                                 hipMemcpyHostToDevice, o->stream));
+        d_sync = (const uint32_t *)o->d_tmp;
+    }
+    rv = smx::launch_pwmosc(o->d_phase, o->d_speed, d_sync, o->d_duty, o->n_pad, n_ticks, o->stream);
+    if (rv) return rv;
+    if (duty)
+        SMX_HIP(hipMemcpy2DAsync(duty, o->n, o->d_duty, o->n_pad, o->n, n_ticks, hipMemcpyDeviceToHost,
+                                 o->stream));
+    SMX_HIP(hipStreamSynchronize(o->stream));
+    return SMX_OK;
+}
+
+extern "C" int smx_osc_events(smx_osc *o, uint32_t n_events, const uint32_t *cc, const uint32_t *valid_bits)
+{
+    if (!o || (n_events && !cc)) return SMX_E_ARG;
+    if (n_events == 0) return SMX_OK;
+    SMX_HIP(hipSetDevice(o->device));
+    int rv = dev_reserve(&o->d_tmp2, &o->tmp2_cap, (size_t)n_events * o->n * 4, o->stream);
+    if (rv) return rv;
+    SMX_HIP(hipMemcpyAsync(o->d_tmp2, cc, (size_t)n_events * o->n * 4, hipMemcpyHostToDevice, o->stream));
+    const uint32_t *d_valid = nullptr;
+    if (valid_bits) {
+        const size_t bytes = (size_t)n_events * ((o->n + 31) / 32) * 4;
+        rv = dev_reserve(&o->d_tmp, &o->tmp_cap, bytes, o->stream);
+        if (rv) return rv;
+        SMX_HIP(hipMemcpyAsync(o->d_tmp, valid_bits, bytes, hipMemcpyHostToDevice, o->stream));
+        d_valid = (const uint32_t *)o->d_tmp;
+    }
+    rv = smx::launch_osc_events(o->pm, (const uint32_t *)o->d_tmp2, d_valid, o->n, n_events, o->log_max, o->stream);
+    if (rv) return rv;
+    SMX_HIP(hipStreamSynchronize(o->stream));
+    return SMX_OK;
+}
+
+static int pmeas_copy(smx_osc *o, const struct smx_pmeas_arrays *a, bool to_device)
+{
+    if (!o || !a) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(o->device));
+    SMX_HIP(hipStreamSynchronize(o->stream));
+    void **slots[9];
+    pmeas_slots(o->pm, slots);
+    void *host[9] = {a->write, a->avg0, a->avg1, a->num0, a->num1, a->num, a->accu, a->last_cc, a->sub};
+    for (int i = 0; i < 9; i++) {
+        if (!host[i]) continue;
+        if (to_device) SMX_HIP(hipMemcpy(*slots[i], host[i], (size_t)o->n * 4, hipMemcpyHostToDevice));
+        else           SMX_HIP(hipMemcpy(host[i], *slots[i], (size_t)o->n * 4, hipMemcpyDeviceToHost));
+    }
+    return SMX_OK;
+}
+
+extern "C" int smx_osc_load_pmeas(smx_osc *o, const struct smx_pmeas_arrays *a) { return pmeas_copy(o, a, true); }
+extern "C" int smx_osc_read_pmeas(smx_osc *o, const struct smx_pmeas_arrays *a) { return pmeas_copy(o, a, false); }

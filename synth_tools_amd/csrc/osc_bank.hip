@@ -1,0 +1,122 @@
+// osc_bank.hip -- oscillator-side banks for gfx950 (MI355X):
+//
+// (1) pwmosc: the hard-synced saw/PWM phase accumulator of
+//     stm32f103/mod_pdm.c:159-175, N voices:
+//         duty  = phase >> 16
+//         phase = (phase + speed + (phase >> 9)) & 0xFFFFFF
+//     with OSC_HARD_SYNC (phase = 0) applied before a tick whenever the
+//     analog oscillator's discharge pulse arrived since the previous tick
+//     (mod_osc.c:60-62: the osc ISR is pre-empted by, hence lands between, PDM
+//     ticks).  The feedback term phase >> 9 makes this a true recurrence in
+//     time, so time stays sequential inside a lane.
+//
+// (2) osc events: the EXTI ISR of stm32f103/mod_osc.c:47-74 with the period
+//     measurement of stm32f103/pmeas.h:64-100, N oscillators, E event slots.
+//
+// Mapping: one lane per oscillator, state in registers for the run.  pwmosc
+// packs 4 adjacent oscillators per lane so a wave writes 256 contiguous duty
+// bytes per tick; sync/valid masks use the pulse-matrix layout of the PDM
+// bank (channel c -> bit c&31 of word c>>5 of a tick/event row).
+#include "smx_common.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool SYNC>
+__global__ __launch_bounds__(256)
+void pwmosc_kernel(uint32_t *__restrict__ phase, const uint32_t *__restrict__ speed,
+                   const uint32_t *__restrict__ sync_bits, uint32_t words_per_row,
+                   uint32_t *__restrict__ duty32, uint32_t ngroups, uint32_t nticks)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= ngroups) return;
+    u32x4 ph = reinterpret_cast<u32x4 *>(phase)[g];
+    const u32x4 sp = reinterpret_cast<const u32x4 *>(speed)[g];
+    const uint32_t word = g >> 3, shift = (g & 7) * 4;      // my 4 sync bits inside a 32-channel word
+    for (uint32_t t = 0; t < nticks; t++) {
+        if (SYNC) {
+            const uint32_t m = sync_bits[(size_t)t * words_per_row + word] >> shift;
+            if (m & 1) ph.x = 0;
+            if (m & 2) ph.y = 0;
+            if (m & 4) ph.z = 0;
+            if (m & 8) ph.w = 0;
+        }
+        const u32x4 d = ph >> 16;
+        duty32[(size_t)t * ngroups + g] =
+            (d.x & 0xFF) | ((d.y & 0xFF) << 8) | ((d.z & 0xFF) << 16) | (d.w << 24);
+        ph = (ph + sp + (ph >> 9)) & 0xFFFFFFu;
+    }
+    reinterpret_cast<u32x4 *>(phase)[g] = ph;
+}
+
+__global__ __launch_bounds__(256)
+void osc_events_kernel(smx::PmeasArrays p, const uint32_t *__restrict__ cc,
+                       const uint32_t *__restrict__ valid_bits, uint32_t words_per_row,
+                       uint32_t n, uint32_t nevents, uint32_t log_max)
+{
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= n) return;
+    uint32_t write = p.write[c], num = p.num[c], accu = p.accu[c], last_cc = p.last_cc[c];
+    uint32_t sub = p.sub[c];
+    uint32_t avg[2] = {p.avg0[c], p.avg1[c]}, npub[2] = {p.num0[c], p.num1[c]};
+    const uint32_t max = 1u << log_max;
+    for (uint32_t e = 0; e < nevents; e++) {
+        if (valid_bits && !((valid_bits[(size_t)e * words_per_row + (c >> 5)] >> (c & 31)) & 1)) continue;
+        sub ^= 1;                                            // sub-osc divide by two, mod_osc.c:65
+        const uint32_t now = cc[(size_t)e * n + c];
+        const uint32_t meas = now - last_cc;                 // pmeas.h:67-68
+        last_cc = now;
+        const uint32_t accu1 = accu + meas;
+        if (accu1 < max) {                                   // pmeas.h:77-80
+            num++;
+            accu = accu1;
+        } else {                                             // pmeas.h:81-100
+            const uint32_t w = write + 1;
+            if (num > 0) {
+                const uint32_t a = (accu << (32 - log_max)) / num;
+                if (w & 1) { avg[1] = a; npub[1] = num; } else { avg[0] = a; npub[0] = num; }
+                write = w;
+            }
+            num = 1;
+            accu = meas;
+        }
+    }
+    p.write[c] = write; p.num[c] = num; p.accu[c] = accu; p.last_cc[c] = last_cc; p.sub[c] = sub;
+    p.avg0[c] = avg[0]; p.avg1[c] = avg[1]; p.num0[c] = npub[0]; p.num1[c] = npub[1];
+}
+
+}  // namespace
+
+namespace smx {
+
+int launch_pwmosc(uint32_t *d_phase, const uint32_t *d_speed, const uint32_t *d_sync_bits,
+                  uint8_t *d_duty, uint32_t n_pad, uint32_t nticks, hipStream_t stream)
+{
+    if (n_pad == 0 || (n_pad & 1023)) { set_error("launch_pwmosc: n_pad=%u", n_pad); return SMX_E_ARG; }
+    if (nticks == 0) return SMX_OK;
+    const uint32_t ngroups = n_pad / 4;
+    const dim3 grid((ngroups + 255) / 256), block(256);
+    auto *o = reinterpret_cast<uint32_t *>(d_duty);
+    if (d_sync_bits)
+        hipLaunchKernelGGL(pwmosc_kernel<true>, grid, block, 0, stream, d_phase, d_speed, d_sync_bits,
+                           n_pad / 32, o, ngroups, nticks);
+    else
+        hipLaunchKernelGGL(pwmosc_kernel<false>, grid, block, 0, stream, d_phase, d_speed, d_sync_bits,
+                           n_pad / 32, o, ngroups, nticks);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_osc_events(const PmeasArrays &p, const uint32_t *d_cc, const uint32_t *d_valid_bits,
+                      uint32_t n, uint32_t nevents, uint32_t log_max, hipStream_t stream)
+{
+    if (n == 0 || log_max == 0 || log_max > 31) { set_error("launch_osc_events: n=%u log_max=%u", n, log_max); return SMX_E_ARG; }
+    if (nevents == 0) return SMX_OK;
+    hipLaunchKernelGGL(osc_events_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, d_cc,
+                       d_valid_bits, (n + 31) / 32, n, nevents, log_max);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+}  // namespace smx

@@ -68,4 +68,13 @@ int launch_pwm_bank(const PwmArrays &p, int order, const uint32_t *d_dither, uin
                     uint32_t n_pad, uint32_t nticks, uint32_t div_count, uint32_t div_log,
                     uint32_t out_shift, hipStream_t stream);
 
+// Oscillator banks (osc_bank.hip).
+struct PmeasArrays {                    // struct pmeas_state (pmeas.h:16-28) + sub-osc bit, SoA
+    uint32_t *write, *avg0, *avg1, *num0, *num1, *num, *accu, *last_cc, *sub;
+};
+int launch_pwmosc(uint32_t *d_phase, const uint32_t *d_speed, const uint32_t *d_sync_bits,
+                  uint8_t *d_duty, uint32_t n_pad, uint32_t nticks, hipStream_t stream);
+int launch_osc_events(const PmeasArrays &p, const uint32_t *d_cc, const uint32_t *d_valid_bits,
+                      uint32_t n, uint32_t nevents, uint32_t log_max, hipStream_t stream);
+
 }  // namespace smx
