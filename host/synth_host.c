@@ -1,0 +1,198 @@
+/* synth_host.c -> host/synth.dynamic.host.elf
+ *
+ * The JACK client of linux/synth.c:214-312, rewritten as host glue over
+ * libsynth_mi355x.so: same client name ("synth"), same ports ("midi_in",
+ * "audio_out"), same callback order (MIDI, then audio: linux/synth.c:277-282),
+ * same life cycle (open, register, set callback, mlockall, activate,
+ * synth_init, then block on a 4-byte stdin read and exit(1):
+ * linux/synth.c:285-312), so that erl/jack_client.erl:63-82 can spawn it
+ * under the same file name with {packet,4} stdio.
+ *
+ * Plain C.  libjack is bound at run time (dlopen) against the public JACK
+ * ABI, because this image has no JACK headers; with --fake-jack the same
+ * process() callback is driven by a scripted block loop instead (the
+ * reference's "stub the environment, run the real code" test pattern,
+ * linux/test_bl_midi.c:5-47).
+ *
+ *   synth.dynamic.host.elf                       real JACK, 64-voice drop-in path
+ *   SYNTH_VOICES=1048576 synth.dynamic.host.elf  real JACK, N-voice bank path
+ *   synth.dynamic.host.elf --fake-jack NBLOCKS NFRAMES EVENTS.bin OUT.f32
+ *       EVENTS.bin: records {u32 block; u8 size; u8 bytes[3]} delivered to
+ *       midi_in at the start of that block; OUT.f32: NBLOCKS*NFRAMES floats.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include "synth_mi355x.h"
+
+#define LOG(...) fprintf(stderr, __VA_ARGS__)
+/* linux/erl_tools_system.h:15,24-27 */
+#define ASSERT(x) do { if (!(x)) { LOG("%s:%d: ASSERT(%s) failed\n", __FILE__, __LINE__, #x); exit(1); } } while (0)
+
+/* ---- the public JACK ABI, as far as linux/synth.c uses it ------------------ */
+typedef uint32_t jack_nframes_t;
+typedef float jack_default_audio_sample_t;
+typedef struct _jack_client jack_client_t;
+typedef struct _jack_port jack_port_t;
+typedef struct { jack_nframes_t time; size_t size; uint8_t *buffer; } jack_midi_event_t;
+typedef int (*JackProcessCallback)(jack_nframes_t nframes, void *arg);
+#define JACK_DEFAULT_AUDIO_TYPE "32 bit float mono audio"
+#define JACK_DEFAULT_MIDI_TYPE "8 bit raw midi"
+enum { JackPortIsInput = 0x1, JackPortIsOutput = 0x2 };
+enum { JackNullOption = 0x00 };
+
+static struct {
+    jack_client_t *(*client_open)(const char *, int, int *, ...);
+    jack_port_t *(*port_register)(jack_client_t *, const char *, const char *, unsigned long, unsigned long);
+    void *(*port_get_buffer)(jack_port_t *, jack_nframes_t);
+    int (*set_process_callback)(jack_client_t *, JackProcessCallback, void *);
+    int (*activate)(jack_client_t *);
+    uint32_t (*midi_get_event_count)(void *);
+    int (*midi_event_get)(jack_midi_event_t *, void *, uint32_t);
+} jack;
+
+/* ---- fake JACK: one MIDI buffer and one audio buffer per block ------------- */
+struct fake_event { uint32_t block; uint8_t size; uint8_t bytes[3]; };
+static struct {
+    int on;
+    struct fake_event *ev; size_t nev, cursor;
+    uint32_t block;
+    jack_midi_event_t cur[1024]; uint32_t ncur;
+    float *audio;
+} fake;
+static jack_port_t *const FAKE_MIDI_PORT = (jack_port_t *)1, *const FAKE_AUDIO_PORT = (jack_port_t *)2;
+
+static void *fake_port_get_buffer(jack_port_t *p, jack_nframes_t n) { (void)n; return p == FAKE_AUDIO_PORT ? (void *)fake.audio : (void *)&fake; }
+static uint32_t fake_midi_get_event_count(void *b) { (void)b; return fake.ncur; }
+static int fake_midi_event_get(jack_midi_event_t *e, void *b, uint32_t i) { (void)b; if (i >= fake.ncur) return -1; *e = fake.cur[i]; return 0; }
+
+/* ---- SYNTH: either the reference's struct synth or an N-voice bank --------- */
+static struct synth synth;               /* linux/synth.c:208 */
+static smx_bank *bank;                   /* SYNTH_VOICES > 64 */
+static jack_port_t *midi_in, *audio_out; /* linux/synth.c:214-221 */
+
+static inline void process_midi(jack_nframes_t nframes) {        /* linux/synth.c:227-260 */
+    void *midi_in_buf = jack.port_get_buffer(midi_in, nframes);
+    jack_nframes_t n = jack.midi_get_event_count(midi_in_buf);
+    for (jack_nframes_t i = 0; i < n; i++) {
+        jack_midi_event_t event;
+        jack.midi_event_get(&event, midi_in_buf, i);
+        const uint8_t *msg = event.buffer;
+        if (!bank) { synth_midi_event(&synth, msg, event.size); continue; }
+        if (event.size != 3) continue;
+        if (msg[0] == 0x90) {
+            if (msg[2] == 0) ASSERT(0 == smx_bank_note_off(bank, msg[1]));
+            else             ASSERT(0 == smx_bank_note_on(bank, msg[1]));
+        } else if (msg[0] == 0x80) {
+            ASSERT(0 == smx_bank_note_off(bank, msg[1]));
+        }
+    }
+}
+static inline void process_audio(jack_nframes_t nframes) {       /* linux/synth.c:261-276 */
+    jack_default_audio_sample_t *dst = jack.port_get_buffer(audio_out, nframes);
+    if (bank) ASSERT(0 == smx_bank_run(bank, dst, NULL, (int)nframes));
+    else      synth_run(&synth, dst, (int)nframes);
+}
+static int process(jack_nframes_t nframes, void *arg) {          /* linux/synth.c:277-282 */
+    (void)arg;
+    /* Order is important. */
+    process_midi(nframes);
+    process_audio(nframes);
+    return 0;
+}
+
+static void bind_jack(void) {
+    void *h = dlopen("libjack.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { LOG("synth: cannot load libjack.so.0 (%s); use --fake-jack\n", dlerror()); exit(1); }
+#define SYM(field, name) ASSERT((*(void **)&jack.field = dlsym(h, name)))
+    SYM(client_open, "jack_client_open");
+    SYM(port_register, "jack_port_register");
+    SYM(port_get_buffer, "jack_port_get_buffer");
+    SYM(set_process_callback, "jack_set_process_callback");
+    SYM(activate, "jack_activate");
+    SYM(midi_get_event_count, "jack_midi_get_event_count");
+    SYM(midi_event_get, "jack_midi_event_get");
+#undef SYM
+}
+
+static void read_fixed(int fd, uint8_t *buf, size_t n) {         /* assert_read, linux/synth.c:308 */
+    while (n) {
+        ssize_t r = read(fd, buf, n);
+        if (r == 0) exit(1);                                     /* EOF: the port was closed */
+        if (r < 0) { if (errno == EINTR) continue; exit(1); }
+        buf += r; n -= (size_t)r;
+    }
+}
+
+int main(int argc, char **argv) {
+    const char *voices_env = getenv("SYNTH_VOICES");
+    uint32_t voices = voices_env ? (uint32_t)strtoul(voices_env, NULL, 0) : 64;
+
+    if (argc >= 2 && !strcmp(argv[1], "--fake-jack")) {
+        ASSERT(argc == 6);
+        uint32_t nblocks = (uint32_t)strtoul(argv[2], NULL, 0), nframes = (uint32_t)strtoul(argv[3], NULL, 0);
+        FILE *f = fopen(argv[4], "rb");
+        ASSERT(f);
+        fseek(f, 0, SEEK_END);
+        long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        fake.nev = (size_t)sz / sizeof(struct fake_event);
+        fake.ev = malloc(sz ? (size_t)sz : 1);
+        ASSERT(fread(fake.ev, sizeof(struct fake_event), fake.nev, f) == fake.nev);
+        fclose(f);
+        fake.audio = malloc(sizeof(float) * nframes);
+        fake.on = 1;
+        jack.port_get_buffer = fake_port_get_buffer;
+        jack.midi_get_event_count = fake_midi_get_event_count;
+        jack.midi_event_get = fake_midi_event_get;
+        midi_in = FAKE_MIDI_PORT;
+        audio_out = FAKE_AUDIO_PORT;
+        if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
+        synth_init(&synth);
+        FILE *out = fopen(argv[5], "wb");
+        ASSERT(out);
+        for (fake.block = 0; fake.block < nblocks; fake.block++) {
+            fake.ncur = 0;
+            while (fake.cursor < fake.nev && fake.ev[fake.cursor].block == fake.block && fake.ncur < 1024) {
+                struct fake_event *e = &fake.ev[fake.cursor++];
+                fake.cur[fake.ncur].time = 0;
+                fake.cur[fake.ncur].size = e->size;
+                fake.cur[fake.ncur].buffer = e->bytes;
+                fake.ncur++;
+            }
+            ASSERT(0 == process(nframes, NULL));
+            ASSERT(fwrite(fake.audio, sizeof(float), nframes, out) == nframes);
+        }
+        fclose(out);
+        LOG("synth: fake-jack rendered %u blocks of %u frames, %u voices\n", nblocks, nframes, voices);
+    } else {
+        /* Jack client setup: linux/synth.c:285-301 */
+        bind_jack();
+        const char *client_name = "synth";
+        int status = 0;
+        jack_client_t *client = jack.client_open(client_name, JackNullOption, &status);
+        ASSERT(client);
+        ASSERT(midi_in = jack.port_register(client, "midi_in", JACK_DEFAULT_MIDI_TYPE, JackPortIsInput, 0));
+        ASSERT(audio_out = jack.port_register(client, "audio_out", JACK_DEFAULT_AUDIO_TYPE, JackPortIsOutput, 0));
+        if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
+        synth_init(&synth);
+        jack.set_process_callback(client, process, 0);
+        ASSERT(!mlockall(MCL_CURRENT | MCL_FUTURE));
+        ASSERT(!jack.activate(client));
+    }
+
+    /* Input loop: only used to signal exit (linux/synth.c:304-310). */
+    for (;;) {
+        uint8_t buf[4];
+        read_fixed(0, buf, sizeof(buf));
+        exit(1);
+    }
+    return 0;
+}

@@ -252,6 +252,47 @@ struct smx_pmeas_arrays {
 int smx_osc_load_pmeas(smx_osc *o, const struct smx_pmeas_arrays *a);
 int smx_osc_read_pmeas(smx_osc *o, const struct smx_pmeas_arrays *a);
 
+/* ======================================================================== */
+/* 7. Firmware control surface, hosted: stm32f103/mod_synth.c:50-137 and the   */
+/*    packet entry stm32f103/synth.c:27-42                                     */
+/* ======================================================================== */
+/* The firmware's `synth_init(struct cbuf*)` / `synth_handle_tag_u32` clash by
+ * name with the Linux `synth_init(struct synth*)`; they live in different
+ * programs in the reference.  Here the firmware side is namespaced smx_fw_*.
+ * The wire layout of TAG_U32 and the parameter-table setter are uc_tools'
+ * (tag_u32.h, parameter.h: not in the reference tree); the layout used here is the
+ * one the reference's own example shows (mod_synth.c:98:
+ * <<16#FFF50002:32, 100:32, 1:32>> = tag:16, nb_from:8, nb_args:8, from[], args[]
+ * big-endian words, then payload bytes). */
+#define SMX_TAG_U32 0xFFF5u              /* erl/jack_client.erl:30 */
+typedef struct smx_fw smx_fw;
+/* firmware synth_init (mod_synth.c:63-86): pdm_init + pdm_start (noise-shaped
+ * PWM bank, the module mod_synth.c:38 compiles), osc_init, controlrate_init.
+ * The reference has 3 channels and 1 oscillator. */
+smx_fw *smx_fw_create(uint32_t n_channels, uint32_t n_oscillators, int device);
+void    smx_fw_destroy(smx_fw *f);
+smx_pwm *smx_fw_pwm(smx_fw *f);          /* borrowed handles */
+smx_osc *smx_fw_osc(smx_fw *f);
+/* synth_handle_tag_u32 (mod_synth.c:89-137), same return codes:
+ * 100 MODE on/off; 101 SETPOINT chan val (-2 bad chan); 102 MEASURE [log_max]
+ * with an optional continuation payload (-3 if more than 2 args); anything else
+ * = parameter table {id, value} (id 0 = osc_setpoint, mod_synth.c:50-56). */
+int smx_fw_handle_tag_u32(smx_fw *f, const uint32_t *args, uint32_t nb_args,
+                          const uint8_t *bytes, uint32_t nb_bytes);
+/* handle_tag (stm32f103/synth.c:27-42) for one {packet,4} payload (without the
+ * 4-byte length): TAG_U32 is dispatched, other tags are logged and ignored. */
+int smx_fw_handle_packet(smx_fw *f, const uint8_t *buf, uint32_t len);
+int smx_fw_running(const smx_fw *f);     /* MODE state (pdm_start/pdm_stop) */
+uint32_t smx_fw_parameter(const smx_fw *f, uint32_t id);
+/* The PDM timer ISR n times (mod_pdm_pwm.c:123-143); returns the number of ticks
+ * executed: n_ticks when running, 0 when stopped; negative on error. */
+int smx_fw_tick_n(smx_fw *f, uint32_t n_ticks, const uint32_t *dither, uint8_t *duty);
+/* osc_poll (mod_osc.c:77-80, pmeas.h:30-61) for one oscillator: returns 1 and the
+ * newly published average when read != write, and hands back the oldest queued
+ * MEASURE continuation (cont_len 0 if none); 0 when nothing is new. */
+int smx_fw_poll(smx_fw *f, uint32_t osc, uint32_t *avg, uint32_t *num,
+                uint8_t *cont, uint32_t cont_cap, uint32_t *cont_len);
+
 #ifdef __cplusplus
 }
 #endif

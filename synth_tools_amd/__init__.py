@@ -131,6 +131,17 @@ ABI = [
     ("smx_osc_events", C.c_int, [_P, C.c_uint32, _P, _P]),
     ("smx_osc_load_pmeas", C.c_int, [_P, C.POINTER(PmeasArrays)]),
     ("smx_osc_read_pmeas", C.c_int, [_P, C.POINTER(PmeasArrays)]),
+    ("smx_fw_create", _P, [C.c_uint32, C.c_uint32, C.c_int]),
+    ("smx_fw_destroy", None, [_P]),
+    ("smx_fw_pwm", _P, [_P]),
+    ("smx_fw_osc", _P, [_P]),
+    ("smx_fw_handle_tag_u32", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32]),
+    ("smx_fw_handle_packet", C.c_int, [_P, _P, C.c_uint32]),
+    ("smx_fw_running", C.c_int, [_P]),
+    ("smx_fw_parameter", C.c_uint32, [_P, C.c_uint32]),
+    ("smx_fw_tick_n", C.c_int, [_P, C.c_uint32, _P, _P]),
+    ("smx_fw_poll", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _P, C.c_uint32,
+                              C.POINTER(C.c_uint32)]),
 ]
 ABI_DATA = ["midi_tab"]
 
@@ -487,3 +498,69 @@ class OscBank:
         st = PmeasArrays(**{k: v.ctypes.data for k, v in out.items()})
         _check(lib().smx_osc_read_pmeas(self._h, C.byref(st)), "smx_osc_read_pmeas")
         return out
+
+
+def tag_u32_packet(args, payload=b"", frm=()):
+    """TAG_U32 frame body: tag:16, nb_from:8, nb_args:8, from[], args[] (big-endian), payload
+    (the layout of the reference's own example, stm32f103/mod_synth.c:98)."""
+    import struct
+    return struct.pack(">HBB", 0xFFF5, len(frm), len(args)) + b"".join(struct.pack(">I", x & 0xFFFFFFFF) for x in tuple(frm) + tuple(args)) + bytes(payload)
+
+
+class Firmware:
+    """Hosted firmware control surface (stm32f103/mod_synth.c:50-137)."""
+
+    def __init__(self, n_channels=3, n_oscillators=1, device=0):
+        self._h = lib().smx_fw_create(n_channels, n_oscillators, device)
+        if not self._h:
+            raise SmxError("smx_fw_create: " + lib().smx_last_error().decode())
+        self.n = n_channels
+        # borrowed views of the module banks
+        self.pwm = PwmBank.__new__(PwmBank)
+        self.pwm._h, self.pwm.n, self.pwm.order = lib().smx_fw_pwm(self._h), n_channels, 2
+        self.osc = None
+        if n_oscillators:
+            self.osc = OscBank.__new__(OscBank)
+            self.osc._h, self.osc.n, self.osc.words = lib().smx_fw_osc(self._h), n_oscillators, (n_oscillators + 31) // 32
+
+    def close(self):
+        if self._h:
+            self.pwm._h = None
+            if self.osc:
+                self.osc._h = None
+            lib().smx_fw_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def handle_tag_u32(self, args, payload=b""):
+        a = np.ascontiguousarray(args, np.uint32)
+        b = np.frombuffer(bytes(payload), np.uint8) if payload else None
+        return lib().smx_fw_handle_tag_u32(self._h, _ptr(a) if len(a) else None, len(a), _ptr(b), 0 if b is None else len(b))
+
+    def handle_packet(self, data):
+        b = np.frombuffer(bytes(data), np.uint8)
+        return lib().smx_fw_handle_packet(self._h, _ptr(b) if len(b) else None, len(b))
+
+    @property
+    def running(self):
+        return bool(lib().smx_fw_running(self._h))
+
+    def parameter(self, i):
+        return lib().smx_fw_parameter(self._h, i)
+
+    def tick_n(self, n_ticks, dither=None):
+        d = None if dither is None else np.ascontiguousarray(dither, np.uint32)
+        duty = np.empty((n_ticks, self.n), np.uint8)
+        ran = lib().smx_fw_tick_n(self._h, n_ticks, _ptr(d), _ptr(duty))
+        if ran < 0:
+            _check(ran, "smx_fw_tick_n")
+        return duty[:ran]
+
+    def poll(self, osc=0):
+        avg, num, ln = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        cont = np.zeros(64, np.uint8)
+        rv = lib().smx_fw_poll(self._h, osc, C.byref(avg), C.byref(num), _ptr(cont), 64, C.byref(ln))
+        if rv < 0:
+            _check(rv, "smx_fw_poll")
+        return None if rv == 0 else (avg.value, num.value, bytes(cont[:ln.value]))

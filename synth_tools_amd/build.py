@@ -44,5 +44,11 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_hosts():
+    """Plain-C host programs over the library (host/*.elf)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(HERE), "host")])
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    build_hosts()

@@ -1,0 +1,142 @@
+"""GPU: the firmware control surface (mod_synth.c:89-137) and the two plain-C host
+programs, end to end through pipes, against the oracle."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import synth_tools_amd as sta
+from synth_tools_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SYNTH_ELF = os.path.join(ROOT, "host", "synth.dynamic.host.elf")
+FW_ELF = os.path.join(ROOT, "host", "fw.dynamic.host.elf")
+
+
+def _oracle_pwm(n):
+    arrs = {k: np.zeros(n, np.uint32) for k in ("setpoint", "pos0", "vel0", "pos1", "vel1", "s1", "s2", "s3", "s4")}
+    arrs["setpoint"][:] = 0x40000000
+    arrs["setpoint"][0] = 2000000000
+    b = oracle.PwmBank(n=n, order=2, div_count=0, div_log=12, out_shift=24,
+                       s=(C.c_void_p * 4)(*[arrs["s%d" % k].ctypes.data for k in (1, 2, 3, 4)]),
+                       **{k: arrs[k].ctypes.data for k in ("setpoint", "pos0", "vel0", "pos1", "vel1")})
+    return b, arrs
+
+
+def test_tag_u32_commands(smx, orc):
+    fw = smx.Firmware(3, 1)
+    assert fw.running                                        # pdm_start at init, mod_synth.c:67
+    assert fw.parameter(0) == 15 << 27                       # osc_setpoint default, mod_synth.c:51
+    # argument errors, mod_synth.c:91,99,106-107,113
+    assert fw.handle_tag_u32([]) == -1
+    assert fw.handle_tag_u32([100]) == -1
+    assert fw.handle_tag_u32([101, 1]) == -1
+    assert fw.handle_tag_u32([101, 3, 5]) == -2
+    assert fw.handle_tag_u32([102, 1, 2]) == -3
+    assert fw.handle_tag_u32([7, 1]) == -1                   # no such parameter
+    # the reference's own example packet: MODE 1 (mod_synth.c:98)
+    assert fw.handle_packet(bytes.fromhex("fff50002" "00000064" "00000001")) == 0 and fw.running
+    assert fw.handle_packet(smx.tag_u32_packet([100, 0])) == 0 and not fw.running
+    assert len(fw.tick_n(100)) == 0                          # stopped: the ISR does not run
+    assert fw.handle_tag_u32([100, 1]) == 0
+    assert fw.handle_packet(smx.tag_u32_packet([0, 0x12345678])) == 0 and fw.parameter(0) == 0x12345678
+    assert fw.handle_packet(b"\xff\xfe\x00\x00") == 0        # unknown tag: logged, ignored (synth.c:39-40)
+    assert fw.handle_packet(b"\xff\xf5\x00\x05\x00") == -1   # truncated
+    # SETPOINT then the ISR against the oracle
+    ob, keep = _oracle_pwm(3)
+    assert fw.handle_packet(smx.tag_u32_packet([101, 2, 0x90000000])) == 0
+    keep["setpoint"][2] = 0x90000000
+    d = synthetic.dither_stream(5000, 3, 0x3FF)
+    got = fw.tick_n(5000, d)
+    want = np.zeros((5000, 3), np.uint8)
+    orc.orc_pwm_bank_run(C.byref(ob), d.ctypes.data, 5000, want.ctypes.data)
+    assert np.array_equal(got, want)
+    fw.close()
+
+
+def test_measure_and_poll(smx, orc):
+    fw = smx.Firmware(3, 1)
+    assert fw.poll() is None
+    assert fw.handle_tag_u32([102, 14], b"pid-A") == 0       # log_max 14 + a continuation
+    assert fw.handle_tag_u32([102], b"pid-B") == 0
+    cc = (np.arange(1, 41, dtype=np.uint32) * 1000).reshape(40, 1)
+    fw.osc.events(cc)
+    p = oracle.Pmeas(log_max=14)
+    for t in cc[:, 0]:
+        orc.orc_osc_event(C.byref(p), int(t))
+    assert p.write == 2
+    first = fw.poll()
+    second = fw.poll()
+    assert first == (p.avg[1], p.num_pub[1], b"pid-A")       # read=1 -> meas[1]
+    assert second == (p.avg[0], p.num_pub[0], b"pid-B")
+    assert fw.poll() is None
+    fw.close()
+
+
+def _events_file(path, events):
+    with open(path, "wb") as f:
+        for blk, msg in events:
+            f.write(struct.pack("<IB3s", blk, len(msg), bytes(msg) + b"\0" * (3 - len(msg))))
+
+
+@pytest.mark.parametrize("voices", [64, 5000])
+def test_synth_host_fake_jack(tmp_path, orc, voices):
+    """linux/synth.c's process() loop, 40 blocks of 64 frames, scripted MIDI, float output
+    compared with the oracle; then the stdin-EOF exit convention (exit status 1)."""
+    events = [(0, [0x90, 60, 100]), (0, [0x90, 64, 100]), (3, [0x90, 67, 90]), (10, [0x80, 64, 0]),
+              (11, [0x90, 60, 0]), (12, [0x80, 99, 0]), (12, [0xB0, 25, 3]), (12, [0x91, 50, 100]),
+              (20, [0x90, 72, 1])] + [(25, [0x90, n, 100]) for n in range(30, 100)]
+    ev, out = tmp_path / "ev.bin", tmp_path / "out.f32"
+    _events_file(ev, events)
+    env = dict(os.environ, SYNTH_VOICES=str(voices))
+    r = subprocess.run([SYNTH_ELF, "--fake-jack", "40", "64", str(ev), str(out)], env=env,
+                       stdin=subprocess.DEVNULL, capture_output=True, timeout=120)
+    assert r.returncode == 1, r.stderr.decode()              # EOF on stdin -> exit(1), linux/synth.c:305-310
+    got = np.fromfile(out, np.float32)
+    n2v = np.zeros(128, np.int32)
+    inc = np.zeros(voices, np.uint32)
+    st = np.zeros(voices, np.uint32)
+    want = []
+    for blk in range(40):
+        for b, msg in events:
+            if b == blk:
+                orc.orc_midi_event(n2v, inc, voices, np.array(msg, np.uint8), 3)
+        want.append(oracle.synth_run(orc, inc, st, 64)[1])
+    assert np.array_equal(got.view(np.uint32), np.concatenate(want).view(np.uint32))
+
+
+def test_fw_host_port_protocol(orc):
+    """{packet,4} on stdin/stdout like an Erlang port (erl/jack_client.erl:63-68)."""
+    p = subprocess.Popen([FW_ELF, "3", "1"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+    def send(body):
+        p.stdin.write(struct.pack(">I", len(body)) + body)
+        p.stdin.flush()
+
+    def ticks(n):
+        send(struct.pack(">HHI", 0xFFFB, 1, n))
+        (ln,) = struct.unpack(">I", p.stdout.read(4))
+        body = p.stdout.read(ln)
+        assert body[:4] == b"\xff\xfb\x00\x01"
+        return np.frombuffer(body[4:], np.uint8).reshape(-1, 3)
+
+    ob, keep = _oracle_pwm(3)
+    want = np.zeros((6000, 3), np.uint8)
+    send(sta.tag_u32_packet([101, 1, 0xB0000000]))
+    keep["setpoint"][1] = 0xB0000000
+    got = ticks(6000)
+    orc.orc_pwm_bank_run(C.byref(ob), None, 6000, want.ctypes.data)
+    assert np.array_equal(got, want)
+    send(sta.tag_u32_packet([100, 0]))                       # MODE 0: pdm_stop
+    assert len(ticks(10)) == 0
+    send(sta.tag_u32_packet([100, 1]))
+    got = ticks(100)
+    orc.orc_pwm_bank_run(C.byref(ob), None, 100, want.ctypes.data)
+    assert np.array_equal(got, want[:100])
+    p.stdin.close()                                          # port_close -> EOF -> exit(1)
+    assert p.wait(timeout=30) == 1
