@@ -25,7 +25,21 @@ namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int ORDER, bool DITHER>
+// v_perm_b32: pick 4 of the 8 bytes of {hi, lo}; selector byte k names the source
+// of result byte k (0-3 = lo bytes, 4-7 = hi bytes, 0x0c = constant 0).
+__device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    (void)hi; (void)lo; (void)sel;
+    return 0;
+#endif
+}
+
+// SH24: out_shift == 24 (the firmware's value): the duty is the top byte of the
+// last integrator, gathered from 4 channels with 3 byte-permutes.
+template <int ORDER, bool DITHER, bool SH24>
 __global__ __launch_bounds__(256)
 void pwm_bank_kernel(smx::PwmArrays p, const uint32_t *__restrict__ dither,
                      uint32_t *__restrict__ duty32,   // [nticks][n_pad/4]
@@ -43,28 +57,53 @@ void pwm_bank_kernel(smx::PwmArrays p, const uint32_t *__restrict__ dither,
 #pragma unroll
     for (int k = 0; k < ORDER; k++) s[k] = reinterpret_cast<const u32x4 *>(p.s[k])[g];
     const uint32_t div_mask = (1u << div_log) - 1;
+    if (SH24) sh = 24;
+    const uint32_t hi_mask = ~0u << sh;               // (q << sh) == s & hi_mask
 
-    for (uint32_t t = 0; t < nticks; t++) {
-        const uint32_t d = DITHER ? dither[t] : 0u;
-        const bool trigger = (div_count == 0);
-        if (trigger) { pos0 = pos1; vel0 = vel1; }           // PDM_COPY_LINE, mod_pdm_pwm.c:118-119
+    // one ISR tick without the control-rate bookkeeping
+    auto tick = [&](uint32_t t) {
+        const uint32_t nd = DITHER ? 0u - dither[t] : 0u;
         pos0 += vel0;                                         // pdm_update_glide, :95-98
-        const u32x4 q = s[ORDER - 1] >> sh;                   // pdm.h: output = quantised last state
-        const u32x4 a = (q << sh) + d;
-        s[0] += pos0 - a;
+        const u32x4 last = s[ORDER - 1];                      // pdm.h: output = quantised last state
+        // a = (q << sh) + dither;  every integrator adds (previous - a): keep -a
+        const u32x4 na = nd - (last & hi_mask);
+        s[0] += pos0 + na;
 #pragma unroll
-        for (int k = 1; k < ORDER; k++) s[k] += s[k - 1] - a;
-        duty32[(size_t)t * ngroups + g] =
-            (q.x & 0xFF) | ((q.y & 0xFF) << 8) | ((q.z & 0xFF) << 16) | (q.w << 24);
-        div_count = (div_count + 1) & div_mask;
-        if (trigger) {                                        // pdm_update_line, mod_controlrate.c:28-40
-            pos1 += vel1 << div_log;
+        for (int k = 1; k < ORDER; k++) s[k] += s[k - 1] + na;
+        uint32_t word;
+        if (SH24) {
+            const uint32_t lo = byte_perm(last.y, last.x, 0x0c0c0703u);   // [x.b3, y.b3, 0, 0]
+            const uint32_t hi = byte_perm(last.w, last.z, 0x07030c0cu);   // [0, 0, z.b3, w.b3]
+            word = lo | hi;
+        } else {
+            const u32x4 q = last >> sh;
+            word = (q.x & 0xFF) | ((q.y & 0xFF) << 8) | ((q.z & 0xFF) << 16) | (q.w << 24);
+        }
+        duty32[(size_t)t * ngroups + g] = word;
+    };
+
+    // Time is cut at the control-rate boundaries (every 1 << div_log ticks) so that the
+    // long runs in between are branch-free and unrollable.
+    uint32_t t = 0;
+    while (t < nticks) {
+        uint32_t seg = min(nticks - t, (div_mask + 1) - div_count);
+        if (div_count == 0) {
+            pos0 = pos1; vel0 = vel1;                         // PDM_COPY_LINE, mod_pdm_pwm.c:118-119
+            tick(t);
+            // control_trigger() -> lower-priority SWI runs after this tick:
+            pos1 += vel1 << div_log;                          // pdm_update_line, mod_controlrate.c:28-40
             const u32x4 span = sp - pos1;
             vel1.x = (uint32_t)((int32_t)span.x >> div_log);
             vel1.y = (uint32_t)((int32_t)span.y >> div_log);
             vel1.z = (uint32_t)((int32_t)span.z >> div_log);
             vel1.w = (uint32_t)((int32_t)span.w >> div_log);
+            t++; seg--;
+            div_count = 1 & div_mask;
         }
+        const uint32_t end = t + seg;
+#pragma unroll 4
+        for (; t < end; t++) tick(t);
+        div_count = (div_count + seg) & div_mask;
     }
     reinterpret_cast<u32x4 *>(p.pos0)[g] = pos0;
     reinterpret_cast<u32x4 *>(p.vel0)[g] = vel0;
@@ -81,12 +120,12 @@ int launch_order(const smx::PwmArrays &p, const uint32_t *d_dither, uint8_t *d_d
     const uint32_t ngroups = n_pad / 4;
     const dim3 grid((ngroups + 255) / 256), block(256);
     auto *o = reinterpret_cast<uint32_t *>(d_duty);
-    if (d_dither)
-        hipLaunchKernelGGL((pwm_bank_kernel<ORDER, true>), grid, block, 0, stream, p, d_dither, o,
-                           ngroups, nticks, div_count, div_log, sh);
-    else
-        hipLaunchKernelGGL((pwm_bank_kernel<ORDER, false>), grid, block, 0, stream, p, d_dither, o,
-                           ngroups, nticks, div_count, div_log, sh);
+#define SMX_PWM_LAUNCH(D, S)                                                                  \
+    hipLaunchKernelGGL((pwm_bank_kernel<ORDER, D, S>), grid, block, 0, stream, p, d_dither, o, \
+                       ngroups, nticks, div_count, div_log, sh)
+    if (d_dither) { if (sh == 24) SMX_PWM_LAUNCH(true, true); else SMX_PWM_LAUNCH(true, false); }
+    else          { if (sh == 24) SMX_PWM_LAUNCH(false, true); else SMX_PWM_LAUNCH(false, false); }
+#undef SMX_PWM_LAUNCH
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
