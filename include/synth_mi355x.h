@@ -293,6 +293,35 @@ int smx_fw_tick_n(smx_fw *f, uint32_t n_ticks, const uint32_t *dither, uint8_t *
 int smx_fw_poll(smx_fw *f, uint32_t osc, uint32_t *avg, uint32_t *num,
                 uint8_t *cont, uint32_t cont_cap, uint32_t *cont_len);
 
+/* ======================================================================== */
+/* 8. cproc dataflow bank: generic/cproc.h:72-155, mod_bpmodular.c:36-45,72-78 */
+/* ======================================================================== */
+/* N instances of one static chain of processors (PROC_COND bindings in allocation
+ * order).  All atoms are uint32 words (cproc.h:128); state starts at zero
+ * (cproc.h:65-66,73). */
+#define SMX_PROC_ACC   1u                /* out += in              (cproc.h:134-144) */
+#define SMX_PROC_EDGE  2u                /* out = in != last; last = in (cproc.h:146-155) */
+#define SMX_CPROC_INPUT(k) (0x80000000u | (uint32_t)(k))   /* external input word k */
+#define SMX_CPROC_MAX_NODES 32
+struct smx_cproc_node {
+    uint32_t proc;                       /* SMX_PROC_*                               */
+    uint32_t in;                         /* SMX_CPROC_INPUT(k) or an earlier node     */
+    uint32_t cond;                       /* subgraph mask: runs when (g & cond) != 0 */
+};
+typedef struct smx_cproc smx_cproc;
+smx_cproc *smx_cproc_create(uint32_t n_instances, const struct smx_cproc_node *nodes,
+                            uint32_t n_nodes, uint32_t n_inputs, int device);
+void smx_cproc_destroy(smx_cproc *c);
+/* n_ticks of cproc_update(input, g) (linux/test_cproc.c:13-17) for every instance.
+ * input: host uint32[n_ticks][n_inputs][n_instances]; g: host uint32[n_ticks] or
+ * NULL (synchronous graph: every node runs); out: host uint32[n_ticks][n_instances]
+ * = `out` of node out_node after each tick (cproc_output), or NULL. */
+int smx_cproc_tick_n(smx_cproc *c, uint32_t n_ticks, const uint32_t *input, const uint32_t *g,
+                     uint32_t out_node, uint32_t *out);
+/* state[node][2][n_instances] = {out, last} */
+int smx_cproc_read_state(smx_cproc *c, uint32_t *state);
+int smx_cproc_load_state(smx_cproc *c, const uint32_t *state);
+
 #ifdef __cplusplus
 }
 #endif

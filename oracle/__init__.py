@@ -41,6 +41,10 @@ class Pmeas(C.Structure):
                 ("sub", C.c_uint32)]
 
 
+class CprocNode(C.Structure):
+    _fields_ = [("proc", C.c_uint32), ("inp", C.c_uint32), ("cond", C.c_uint32)]
+
+
 class PolyBank(C.Structure):
     _fields_ = [("n", C.c_uint32)] + [(k, C.c_void_p) for k in
                 ("inc", "phase", "y", "a", "level", "stage", "gate", "ar", "dr", "sl", "rr", "pan")]
@@ -74,6 +78,8 @@ def load():
     lib.orc_osc_bank_events.argtypes = [C.POINTER(Pmeas), C.c_uint32, _u32p, C.c_void_p, C.c_uint32]
     lib.orc_acc_update.argtypes = [_u32p, C.c_uint32]
     lib.orc_edge_update.argtypes = [_u32p, _u32p, C.c_uint32]
+    lib.orc_cproc_run.argtypes = [C.POINTER(CprocNode), C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p,
+                                  C.c_void_p, C.c_uint32, C.c_uint32, _u32p]
     lib.orc_poly_run.argtypes = [C.POINTER(PolyBank), _i32p, C.c_int]
     return lib
 

@@ -322,6 +322,28 @@ void orc_edge_update(uint32_t *out, uint32_t *last, uint32_t in) {
     *last = in;
 }
 
+void orc_cproc_run(const struct orc_cproc_node *nodes, uint32_t n_nodes, uint32_t n_inst,
+                   uint32_t n_inputs, uint32_t *state, const uint32_t *input,
+                   const uint32_t *g, uint32_t nticks, uint32_t out_node, uint32_t *out) {
+    for (uint32_t t = 0; t < nticks; t++) {
+        uint32_t gt = g ? g[t] : 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < n_inst; i++) {
+            for (uint32_t k = 0; k < n_nodes; k++) {            /* allocation order */
+                if (!(gt & nodes[k].cond)) continue;             /* PROC_COND */
+                uint32_t src = nodes[k].in;
+                uint32_t in = (src & ORC_CPROC_INPUT)
+                    ? input[((size_t)t * n_inputs + (src & 0x7FFFFFFFu)) * n_inst + i]
+                    : state[((size_t)src * 2 + 0) * n_inst + i];
+                uint32_t *o = &state[((size_t)k * 2 + 0) * n_inst + i];
+                uint32_t *l = &state[((size_t)k * 2 + 1) * n_inst + i];
+                if (nodes[k].proc == ORC_PROC_ACC) orc_acc_update(o, in);
+                else if (nodes[k].proc == ORC_PROC_EDGE) orc_edge_update(o, l, in);
+            }
+            if (out) out[(size_t)t * n_inst + i] = state[((size_t)out_node * 2) * n_inst + i];
+        }
+    }
+}
+
 /* ======================================================================== */
 /* poly voice -- BUILD-DEFINED EXTENSION; no reference.  */
 /* ======================================================================== */

@@ -115,6 +115,19 @@ void orc_osc_bank_events(struct orc_pmeas *p, uint32_t n, const uint32_t *cc,
 void orc_acc_update(uint32_t *out, uint32_t in);                     /* :142-144 */
 void orc_edge_update(uint32_t *out, uint32_t *last, uint32_t in);    /* :152-155 */
 
+/* N independent instances of one static PROC chain (cproc.h:72-81 PROC_COND in A-normal
+ * form; mod_bpmodular.c:72-78 runs instances in allocation order).  Node k reads either
+ * an external input (in = ORC_CPROC_INPUT | index) or the `out` of an earlier node, and
+ * runs only when (g[t] & cond) != 0.  input[t][n_inputs][n_inst], out[t][n_inst] = the
+ * `out` of node out_node after tick t.  state[node][2][n_inst] = {out, last}. */
+#define ORC_CPROC_INPUT 0x80000000u
+enum { ORC_PROC_ACC = 1, ORC_PROC_EDGE = 2 };
+struct orc_cproc_node { uint32_t proc, in, cond; };
+void orc_cproc_run(const struct orc_cproc_node *nodes, uint32_t n_nodes, uint32_t n_inst,
+                   uint32_t n_inputs, uint32_t *state, const uint32_t *input,
+                   const uint32_t *g /* per tick, NULL = all ones */, uint32_t nticks,
+                   uint32_t out_node, uint32_t *out);
+
 /* ---- poly voice: BUILD-DEFINED EXTENSION (no reference counterpart) ----- */
 /* Stage codes */
 enum { ORC_ENV_IDLE = 0, ORC_ENV_A = 1, ORC_ENV_D = 2, ORC_ENV_S = 3, ORC_ENV_R = 4 };

@@ -48,6 +48,17 @@ class PmeasArrays(C.Structure):      # struct smx_pmeas_arrays
     _fields_ = [(k, C.c_void_p) for k in PMEAS_FIELDS]
 
 
+class CprocNode(C.Structure):        # struct smx_cproc_node
+    _fields_ = [("proc", C.c_uint32), ("inp", C.c_uint32), ("cond", C.c_uint32)]
+
+
+PROC_ACC, PROC_EDGE = 1, 2
+
+
+def cproc_input(k):
+    return 0x80000000 | k
+
+
 class PwmArrays(C.Structure):        # struct smx_pwm_arrays
     _fields_ = [(k, C.c_void_p) for k in ("setpoint", "pos0", "vel0", "pos1", "vel1")] + [("s", C.c_void_p * 4)]
 
@@ -131,6 +142,11 @@ ABI = [
     ("smx_osc_events", C.c_int, [_P, C.c_uint32, _P, _P]),
     ("smx_osc_load_pmeas", C.c_int, [_P, C.POINTER(PmeasArrays)]),
     ("smx_osc_read_pmeas", C.c_int, [_P, C.POINTER(PmeasArrays)]),
+    ("smx_cproc_create", _P, [C.c_uint32, C.POINTER(CprocNode), C.c_uint32, C.c_uint32, C.c_int]),
+    ("smx_cproc_destroy", None, [_P]),
+    ("smx_cproc_tick_n", C.c_int, [_P, C.c_uint32, _P, _P, C.c_uint32, _P]),
+    ("smx_cproc_read_state", C.c_int, [_P, _P]),
+    ("smx_cproc_load_state", C.c_int, [_P, _P]),
     ("smx_fw_create", _P, [C.c_uint32, C.c_uint32, C.c_int]),
     ("smx_fw_destroy", None, [_P]),
     ("smx_fw_pwm", _P, [_P]),
@@ -564,3 +580,36 @@ class Firmware:
         if rv < 0:
             _check(rv, "smx_fw_poll")
         return None if rv == 0 else (avg.value, num.value, bytes(cont[:ln.value]))
+
+
+class CprocBank:
+    """N instances of one static cproc chain (generic/cproc.h PROC_COND bindings)."""
+
+    def __init__(self, n_instances, nodes, n_inputs, device=0):
+        arr = (CprocNode * len(nodes))(*[CprocNode(*nd) for nd in nodes])
+        self._h = lib().smx_cproc_create(n_instances, arr, len(nodes), n_inputs, device)
+        if not self._h:
+            raise SmxError("smx_cproc_create: " + lib().smx_last_error().decode())
+        self.n, self.n_nodes, self.n_inputs = n_instances, len(nodes), n_inputs
+
+    def close(self):
+        if self._h:
+            lib().smx_cproc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def tick_n(self, input, g=None, out_node=None):
+        inp = np.ascontiguousarray(input, np.uint32)
+        nt = inp.size // (self.n_inputs * self.n)
+        gg = None if g is None else np.ascontiguousarray(g, np.uint32)
+        out = np.empty((nt, self.n), np.uint32)
+        _check(lib().smx_cproc_tick_n(self._h, nt, _ptr(inp), _ptr(gg),
+                                      self.n_nodes - 1 if out_node is None else out_node, _ptr(out)),
+               "smx_cproc_tick_n")
+        return out
+
+    def read_state(self):
+        st = np.empty((self.n_nodes, 2, self.n), np.uint32)
+        _check(lib().smx_cproc_read_state(self._h, _ptr(st)), "smx_cproc_read_state")
+        return st

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsynth_mi355x.so")
-SOURCES = ["saw_bank.hip", "pdm_bank.hip", "poly_bank.hip", "pwm_bank.hip", "osc_bank.hip", "abi.cpp"]
+SOURCES = ["saw_bank.hip", "pdm_bank.hip", "poly_bank.hip", "pwm_bank.hip", "osc_bank.hip", "cproc_bank.hip", "abi.cpp"]
 HEADERS = ["smx_common.h", os.path.join("..", "..", "include", "synth_mi355x.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-result"]

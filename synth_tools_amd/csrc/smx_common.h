@@ -77,4 +77,15 @@ int launch_pwmosc(uint32_t *d_phase, const uint32_t *d_speed, const uint32_t *d_
 int launch_osc_events(const PmeasArrays &p, const uint32_t *d_cc, const uint32_t *d_valid_bits,
                       uint32_t n, uint32_t nevents, uint32_t log_max, hipStream_t stream);
 
+// cproc dataflow bank (cproc_bank.hip)
+#define SMX_CPROC_MAX_NODES 32
+struct CprocNode { uint32_t proc, in, cond; };
+struct CprocProgram {
+    uint32_t n_nodes, n_inputs;
+    CprocNode nodes[SMX_CPROC_MAX_NODES];
+};
+int launch_cproc(const CprocProgram &prog, uint32_t *d_state, const uint32_t *d_input,
+                 const uint32_t *d_g, uint32_t *d_out, uint32_t n_pad, uint32_t nticks,
+                 uint32_t out_node, hipStream_t stream);
+
 }  // namespace smx
