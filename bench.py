@@ -158,6 +158,23 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
                     "ms_per_step": round(ms, 4), "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
                     "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     p.close()
+    # noise-shaped PWM bank (mod_pdm_pwm.c: pdm2 + glide + control rate), 1 Mi channels
+    n, nt = 1 << 20, 1024
+    w = sta.PwmBank(n, order=2)
+    w.load(setpoint=synthetic.pdm_bank(n, 0x5EED0008)[0])
+    w.tick_n(8, synthetic.dither_stream(8, 7, 0x3FF), want_duty=False)
+    w.tick_n_async(nt, True)
+    w.sync()
+    w.timer_start()
+    for _ in range(5):
+        w.tick_n_async(nt, True)
+    ms = w.timer_stop() / 5
+    w.close()
+    alg = 52.0 * n + float(nt) * n
+    out.append({"workload": "noise-shaped PWM bank (pdm2+glide), %d channels, %d ticks/launch, dither seeded" % (n, nt),
+                "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
+                "ms_per_step": round(ms, 4), "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
+                "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     # BASELINE config 4: 256 Ki poly voices (saw + 1-pole LPF + ADSR + stereo mix; build-defined)
     n = 1 << 18
     pb = sta.PolyBank(n)
