@@ -160,6 +160,7 @@ struct smx_bank {
     int bus_cur = 0;
     uint32_t bus_cap = 0;
     int32_t *h_bus = nullptr;                    // pinned
+    void *d_scratch = nullptr;                   // partial sums of saw_bank.hip's carry formulation
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     hipEvent_t ev_kernel[NBUS] = {nullptr, nullptr, nullptr};   // kernel of bus[i] finished
@@ -188,6 +189,12 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
     if (b->h_bus) SMX_HIP(hipHostFree(b->h_bus));
     b->h_bus = nullptr;
     SMX_HIP(hipHostMalloc((void **)&b->h_bus, (size_t)cap * 4, hipHostMallocDefault));
+    if (b->d_scratch) SMX_HIP(hipFree(b->d_scratch));
+    b->d_scratch = nullptr;
+    if (b->n_pad >= (1u << 20)) {
+        SMX_HIP(hipMalloc(&b->d_scratch, smx::saw_scratch_bytes(cap)));
+        SMX_HIP(hipMemset(b->d_scratch, 0, smx::saw_scratch_bytes(cap)));   // slots are kept zero between launches
+    }
     b->bus_cap = cap;
     return SMX_OK;
 }
@@ -250,6 +257,7 @@ extern "C" void smx_bank_destroy(smx_bank *b)
         if (b->ev_comm[i]) (void)hipEventDestroy(b->ev_comm[i]);
     }
     if (b->h_bus) (void)hipHostFree(b->h_bus);
+    if (b->d_scratch) (void)hipFree(b->d_scratch);
     if (b->ev_t0) (void)hipEventDestroy(b->ev_t0);
     if (b->ev_t1) (void)hipEventDestroy(b->ev_t1);
     if (b->comm_stream) (void)hipStreamDestroy(b->comm_stream);
@@ -352,7 +360,7 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
     rv = bank_bus_advance(b, (uint32_t)n, &bi, &bnext);
     if (rv) return rv;
     rv = smx::launch_saw_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1], b->d_bus[bi],
-                              b->d_bus[bnext], b->n_pad, (uint32_t)n, b->stream);
+                              b->d_bus[bnext], b->n_pad, (uint32_t)n, b->d_scratch, b->stream);
     if (rv) return rv;
     b->bus_zeroed[bi] = 0;                 // now holds this block's sums
     b->bus_zeroed[bnext] = (uint32_t)n;    // cleared by the launch

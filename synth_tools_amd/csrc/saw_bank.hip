@@ -19,6 +19,21 @@
 // state(t0) = state + t0*inc (mod 2^32), so chunks are independent and small
 // banks still fill the chip.  State is ping-ponged (state_in -> state_out) so
 // that chunks never read what another chunk has already advanced.
+//
+// Long blocks of big banks (> 32 frames, >= 2^20 voices) take a second formulation
+// (saw_bank_carry_kernel) that needs 2 instead of 2.5 vector ops per voice-sample:
+// with u = state ^ 0x80000000 (offset binary) the arithmetic shift becomes a logical
+// one, (int)state >> 4 == (u >> 4) - 2^27, and because every term is a floor,
+//     sum_v (u_v >> 4) == (sum_v u_v - sum_v (u_v & 15)) >> 4        exactly.
+// sum_v u_v(t) == U0 + t*I - 2^32 * W(t) with U0 = sum u_v(t0), I = sum inc_v and
+// W(t) = number of 32-bit wraps of all phases before frame t; the low nibbles
+// (u_v(t) & 15) == ((u_v(t0) & 15) + t*(inc_v & 15)) & 15 depend on 8 bits per voice,
+// so their sum comes from a 256-bin histogram.  Per voice-sample only the phase add
+// and the count of its carry-out remain: v_add_co + v_addc (two of four voices) or
+// v_add_co + s_bcnt1 on the carry mask (the other two: the scalar unit works beside
+// the vector unit).  Everything is reduced in integers, so the result is the same
+// bits as the reference loop; a small second kernel combines the per-workgroup
+// partial sums into the int32 bus.
 #include "smx_common.h"
 
 namespace {
@@ -122,6 +137,205 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     if (q == 0 && t < TC && t0 + t < nframes) atomicAdd(&bus[t0 + t], s);
 }
 
+// ---------------------------------------------------------------------------
+// carry-count formulation (see the header comment)
+// ---------------------------------------------------------------------------
+// Partial sums of one 64-frame chunk.  Workgroups add into one of a few slots per chunk
+// (few adders per address); saw_bank_finalize_kernel sums the slots and clears them.
+constexpr int SAW_SLOTS = 64;       // slots per chunk (unused ones stay zero)
+struct SawPartial {
+    unsigned long long L[64];     // sum over voices of (u_v(t) & 15)
+    unsigned long long U0, I;     // sum u_v(t0), sum inc_v
+    uint32_t W[64];               // carries out of the phase add at frame t (t -> t+1)
+};
+
+// Four voices advance one frame: 4 x v_add_co_u32 (carry-outs as SGPR masks).  The
+// carries of voices 0/1 are counted per lane by v_addc_co_u32; those of voices 2/3
+// are returned as a scalar population count.  All SGPR masks are consumed >= 3
+// instructions after they are written (gfx950 needs 2 wait states between a VALU
+// SGPR write and a VALU read; scalar reads are interlocked).
+__device__ __forceinline__ uint32_t carry_step4(uint32_t &u0, uint32_t &u1, uint32_t &u2, uint32_t &u3,
+                                                uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3,
+                                                uint32_t &cnt)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long m0, m1, m2, m3;
+    asm("v_add_co_u32_e64 %0, %5, %0, %9\n\t"
+        "v_add_co_u32_e64 %1, %6, %1, %10\n\t"
+        "v_add_co_u32_e64 %2, %7, %2, %11\n\t"
+        "v_add_co_u32_e64 %3, %8, %3, %12\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %5\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %6"
+        : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(cnt), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(i0), "v"(i1), "v"(i2), "v"(i3)
+        : "vcc");
+    return (uint32_t)(__builtin_popcountll(m2) + __builtin_popcountll(m3));
+#else
+    (void)u0; (void)u1; (void)u2; (void)u3; (void)i0; (void)i1; (void)i2; (void)i3; (void)cnt;
+    return 0;
+#endif
+}
+
+// MULTI: more than one 64-frame chunk per launch (blockIdx.y); only chunk 0 writes the
+// advanced phases.  The single-chunk form keeps its memory operations in straight-line
+// order (load, load, store) so that the wait for the prefetched loads is vmcnt(1) and the
+// store's completion is never waited for inside the loop.
+template <bool NT, bool MULTI>
+__global__ __launch_bounds__(256)
+void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
+                           uint32_t *__restrict__ st_out, SawPartial *__restrict__ partial,
+                           uint32_t ngroups, uint32_t nframes)
+{
+    __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
+    __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
+    __shared__ unsigned long long S[2];            // U0, I
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t t0 = blockIdx.y * 64u;
+    for (uint32_t i = tid; i < 64 * 65; i += 256) (&M[0][0])[i] = 0;
+    H[tid] = 0;
+    if (tid < 2) S[tid] = 0;
+    __syncthreads();
+
+    uint32_t cnt[64];                              // per-lane carry counts (voices 0/1)
+    uint32_t W[32];                                // wave-uniform counts (voices 2/3): frames t | t+32 << 16
+#pragma unroll
+    for (int t = 0; t < 64; t++) cnt[t] = 0;
+#pragma unroll
+    for (int t = 0; t < 32; t++) W[t] = 0;
+    unsigned long long sumU = 0, sumI = 0;
+
+    // ngroups is a multiple of 256 (n_pad of 1024): whole workgroup rows, so the trip count is
+    // wave-uniform and the scalar counters W stay in SGPRs
+    const uint32_t nrows = ngroups >> 8;
+    // software prefetch: the next row's 32 bytes per lane are requested before the ~6000
+    // cycles of arithmetic on the current row, so HBM latency never sits on the critical path
+    const u32x4 *inc4 = reinterpret_cast<const u32x4 *>(inc);
+    const u32x4 *st4 = reinterpret_cast<const u32x4 *>(st_in);
+    u32x4 a_next = 0, b_next = 0;
+    if (blockIdx.x < nrows) {
+        a_next = stream_load<NT>(inc4 + blockIdx.x * 256u + tid);
+        b_next = stream_load<NT>(st4 + blockIdx.x * 256u + tid);
+    }
+    for (uint32_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const uint32_t g = row * 256u + tid;
+        const u32x4 a = a_next, b = b_next;
+        // unconditional prefetch (the last trip re-reads its own row): no branch, no join
+        const uint32_t rn = min(row + gridDim.x, nrows - 1) * 256u + tid;
+        a_next = stream_load<NT>(inc4 + rn);
+        b_next = stream_load<NT>(st4 + rn);
+        // keep the store the YOUNGEST memory operation of the trip (vmcnt retires in order)
+        asm volatile("" ::: "memory");
+        if (!MULTI || blockIdx.y == 0)
+            stream_store<NT>(b + nframes * a, reinterpret_cast<u32x4 *>(st_out) + g);
+        // an inactive voice (inc == 0) is parked at phase 0: it contributes (0 >> 4) = 0
+        uint32_t u0 = (a.x ? b.x + t0 * a.x : 0u) ^ 0x80000000u;
+        uint32_t u1 = (a.y ? b.y + t0 * a.y : 0u) ^ 0x80000000u;
+        uint32_t u2 = (a.z ? b.z + t0 * a.z : 0u) ^ 0x80000000u;
+        uint32_t u3 = (a.w ? b.w + t0 * a.w : 0u) ^ 0x80000000u;
+        sumU += (unsigned long long)u0 + u1 + u2 + u3;
+        sumI += (unsigned long long)a.x + a.y + a.z + a.w;
+        atomicAdd(&H[((u0 & 15) << 4) | (a.x & 15)], 1u);
+        atomicAdd(&H[((u1 & 15) << 4) | (a.y & 15)], 1u);
+        atomicAdd(&H[((u2 & 15) << 4) | (a.z & 15)], 1u);
+        atomicAdd(&H[((u3 & 15) << 4) | (a.w & 15)], 1u);
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+            const uint32_t c = carry_step4(u0, u1, u2, u3, a.x, a.y, a.z, a.w, cnt[t]);
+            W[t & 31] += (t < 32) ? c : (c << 16);
+        }
+    }
+
+    // per-lane counts -> M[t][lane]; per-wave scalar counts -> M[t][64]
+#pragma unroll
+    for (int t = 0; t < 64; t++) atomicAdd(&M[t][lane], cnt[t]);
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 32; t++) {
+            atomicAdd(&M[t][64], W[t] & 0xFFFFu);
+            atomicAdd(&M[t + 32][64], W[t] >> 16);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { sumU += __shfl_xor(sumU, o); sumI += __shfl_xor(sumI, o); }
+    if (lane == 0) { atomicAdd(&S[0], sumU); atomicAdd(&S[1], sumI); }
+    __syncthreads();
+
+    SawPartial *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
+    {   // carries per frame: 4 lanes x 16 columns (+ column 64)
+        const uint32_t t = tid >> 2, q = tid & 3;
+        uint32_t s = (q == 0) ? M[t][64] : 0u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += M[t][q * 16 + j];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (q == 0) atomicAdd(&out->W[t], s);
+    }
+    {   // low-nibble sums per frame from the histogram: 4 lanes x 64 bins per frame
+        const uint32_t t = tid >> 2, q = tid & 3;
+        unsigned long long l = 0;
+        for (uint32_t k = 0; k < 64; k++) {
+            const uint32_t bin = q * 64 + k;
+            l += (unsigned long long)H[bin] * (((bin >> 4) + t * (bin & 15)) & 15);
+        }
+        l += __shfl_xor(l, 1);
+        l += __shfl_xor(l, 2);
+        if (q == 0) atomicAdd(&out->L[t], l);
+    }
+    if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicAdd(&out->I, S[1]); }
+}
+
+// One workgroup per 64-frame chunk: add the chunk's slots (and clear them for the next
+// launch) and emit
+//   bus[t0+t] = ((U0 + t*I - 2^32*W(t) - L(t)) >> 4) - nvoices * 2^27        (mod 2^32)
+__global__ __launch_bounds__(256)
+void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
+                              int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
+                              uint32_t nframes, uint32_t nvoices)
+{
+    __shared__ unsigned long long Ls[4][64], Us[4][2];
+    __shared__ uint32_t Ws[4][64];
+    const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
+    SawPartial *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
+    // all loads first (16 independent ones per thread in flight), then the clearing stores
+    unsigned long long lv[SAW_SLOTS / 4], uv[SAW_SLOTS / 4], iv[SAW_SLOTS / 4];
+    uint32_t wv[SAW_SLOTS / 4];
+#pragma unroll
+    for (int k = 0; k < SAW_SLOTS / 4; k++) {
+        const SawPartial *q = p + part + 4 * k;
+        lv[k] = q->L[t];
+        wv[k] = q->W[t];
+        uv[k] = (t == 0) ? q->U0 : 0ull;
+        iv[k] = (t == 0) ? q->I : 0ull;
+    }
+    unsigned long long l = 0, u0 = 0, ii = 0;
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < SAW_SLOTS / 4; k++) {
+        SawPartial *q = p + part + 4 * k;
+        l += lv[k]; w += wv[k]; u0 += uv[k]; ii += iv[k];
+        q->L[t] = 0;
+        q->W[t] = 0;
+        if (t == 0) { q->U0 = 0; q->I = 0; }
+    }
+    Ls[part][t] = l;
+    Ws[part][t] = w;
+    if (t == 0) { Us[part][0] = u0; Us[part][1] = ii; }
+    __syncthreads();
+    if (part == 0) {
+        const unsigned long long L = Ls[0][t] + Ls[1][t] + Ls[2][t] + Ls[3][t];
+        const unsigned long long U0 = Us[0][0] + Us[1][0] + Us[2][0] + Us[3][0];
+        const unsigned long long I = Us[0][1] + Us[1][1] + Us[2][1] + Us[3][1];
+        uint32_t wraps = 0;                         // W(t): carries of frames before t (mod 16 matters)
+        for (uint32_t k = 0; k < t; k++) wraps += Ws[0][k] + Ws[1][k] + Ws[2][k] + Ws[3][k];
+        const unsigned long long x = U0 + (unsigned long long)t * I - ((unsigned long long)(wraps & 15u) << 32) - L;
+        const uint32_t r = (uint32_t)(x >> 4) - (nvoices << 27);
+        const uint32_t f = blockIdx.x * 64u + t;
+        if (f < nframes) {
+            bus[f] = (int32_t)r;
+            bus_next[f] = 0;                        // same contract as saw_bank_kernel
+        }
+    }
+}
+
 // sum_tick_square (linux/synth.c:182-195): OR of the active voices' sign bits.
 // Unused by the reference's synth_run; kept as a bank variant.  bus word t
 // receives 0x80000000 if any active voice has its sign bit set at frame t.
@@ -198,13 +412,48 @@ int launch_vw(const uint32_t *inc, const uint32_t *si, uint32_t *so, int32_t *bu
 
 namespace smx {
 
+size_t saw_scratch_bytes(uint32_t max_frames)
+{
+    return (size_t)SAW_SLOTS * ((max_frames + 63) / 64 + 1) * sizeof(SawPartial);
+}
+
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
                     uint32_t *d_state_out, int32_t *d_bus, int32_t *d_bus_next,
-                    uint32_t n_pad, uint32_t nframes, hipStream_t stream)
+                    uint32_t n_pad, uint32_t nframes, void *d_scratch, hipStream_t stream)
 {
     if (n_pad == 0 || (n_pad & 1023) || nframes == 0) {
         set_error("launch_saw_bank: n_pad=%u nframes=%u", n_pad, nframes);
         return SMX_E_ARG;
+    }
+    static const bool no_carry = getenv("SMX_SAW_NO_CARRY") != nullptr;      // A/B switch
+    // measured crossover on MI355X: the carry formulation's fixed cost (histogram fold, slot
+    // atomics, second kernel) pays off from about 2^31 voice-samples per launch
+    const bool big = (unsigned long long)n_pad * nframes >= (1ull << 31);
+    if (nframes > 32 && n_pad >= (1u << 20) && big && d_scratch && !no_carry) {
+        // carry-count formulation: 2 vector ops per voice-sample
+        const uint32_t ngroups = n_pad / 4;
+        const uint32_t gy = (nframes + 63) / 64;
+        static const char *cg = getenv("SMX_SAW_CARRY_GRID");           // tuning override
+        const uint32_t total = cg ? (uint32_t)atoi(cg) : 4096u;
+        uint32_t gx = (total + gy - 1) / gy;
+        if (gx > (ngroups + 255) / 256) gx = (ngroups + 255) / 256;
+        // the packed 16-bit scalar counters take 128 carries per trip: stay below 400 trips
+        // (banks that would need more workgroups than the scratch holds use the direct form)
+        const uint32_t trips = (ngroups + gx * 256u - 1) / (gx * 256u);
+        if (trips <= 400 && (size_t)SAW_SLOTS * gy * sizeof(SawPartial) <= saw_scratch_bytes(nframes)) {
+            auto *part = static_cast<SawPartial *>(d_scratch);     // all zero between launches
+#define SMX_CARRY_LAUNCH(NT_, MULTI_)                                                             \
+    hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_>), dim3(gx, gy), dim3(256), 0, stream, \
+                       d_inc, d_state_in, d_state_out, part, ngroups, nframes)
+            const bool nt = n_pad >= (1u << 24);
+            if (gy == 1) { if (nt) SMX_CARRY_LAUNCH(true, false); else SMX_CARRY_LAUNCH(false, false); }
+            else         { if (nt) SMX_CARRY_LAUNCH(true, true);  else SMX_CARRY_LAUNCH(false, true); }
+#undef SMX_CARRY_LAUNCH
+            hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
+                               d_bus_next, nframes, n_pad);
+            SMX_HIP(hipGetLastError());
+            return SMX_OK;
+        }
     }
     // 4 voices per lane once there are enough voices to fill the chip that way;
     // non-temporal streaming once the bank (12 B/voice) cannot live in the 256 MiB

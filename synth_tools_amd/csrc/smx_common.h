@@ -39,9 +39,13 @@ static inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m
 // ---- kernel launchers (defined in the .hip files) --------------------------
 // Saw bank (saw_bank.hip).  n_pad is a multiple of 1024; d_bus[0..nframes) must be zero
 // on entry; the launch zeroes d_bus_next[0..nframes) for its successor.
+// d_scratch: saw_scratch_bytes(max frames) bytes of ZEROED device memory (partial-sum slots
+// of the carry formulation; each launch leaves them zero again), or NULL to force the
+// direct formulation.
+size_t saw_scratch_bytes(uint32_t max_frames);
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
                     uint32_t *d_state_out, int32_t *d_bus, int32_t *d_bus_next,
-                    uint32_t n_pad, uint32_t nframes, hipStream_t stream);
+                    uint32_t n_pad, uint32_t nframes, void *d_scratch, hipStream_t stream);
 int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
                        uint32_t *d_state_out, uint32_t *d_or_bus, uint32_t n_pad,
                        uint32_t nframes, hipStream_t stream);

@@ -183,3 +183,27 @@ def test_rccl_allreduce_path_single_rank(smx, orc, inc_table):
     bus, vec = bank.fetch(64)
     assert np.array_equal(bus, want) and np.array_equal(vec.view(np.uint32), wvec.view(np.uint32))
     bank.close()
+
+
+@pytest.mark.parametrize("frac", [1.0, 0.5, 0.0])
+def test_carry_formulation_blocks(smx, orc, inc_table, frac):
+    """> 32 frames on >= 2^20 voices run the carry-count formulation (saw_bank.hip):
+    full and partial chunks, several chunks per launch, mixed with short blocks that take
+    the direct formulation on the same bank."""
+    n = (1 << 25) + 1000          # n * frames >= 2^31 selects the carry formulation for >= 64 frames
+    inc, state = synthetic.saw_bank(n, 0x5EED0C00, inc_table, active_fraction=frac)
+    _check(smx, orc, inc, state, [64, 1, 65, 16, 100])
+
+
+def test_carry_formulation_extreme_increments(smx, orc):
+    """Increments that wrap the phasor every frame (0xFFFFFFFF), never (1), and low-nibble
+    patterns of every (phase & 15, inc & 15) class."""
+    n = 1 << 25
+    k = np.arange(n, dtype=np.uint64)
+    inc = np.where(k % 3 == 0, 0xFFFFFFFF, np.where(k % 3 == 1, 1, (k * 2654435761) & 0xFFFFFFFF)).astype(np.uint32)
+    state = ((k * 40503 + 12345) & 0xFFFFFFFF).astype(np.uint32)
+    _check(smx, orc, inc, state, [64, 130])
+    _check(smx, orc, np.full(n, 0x80000000, np.uint32), np.full(n, 0x7FFFFFFF, np.uint32), [64, 64])
+    # 2^22 voices x 600 frames: many chunks per launch (MULTI form), 2.5e9 voice-samples
+    m = 1 << 22
+    _check(smx, orc, np.ascontiguousarray(inc[:m]), np.ascontiguousarray(state[:m]), [600, 513])
