@@ -118,14 +118,17 @@ def time_saw(sta, bank, frames, steps, warmup, comm=False):
 def also_workloads(sta, synthetic, tab, big_bank, voices):
     out = []
     # the JACK operating point (48 kHz, 64 frames: linux/jack_midi.c:19-20) on the same bank
-    for frames in (16, 64):
-        ms = time_saw(sta, big_bank, frames, 50, 5)
+    for frames in (16, 32, 64, 1024):
+        ms = time_saw(sta, big_bank, frames, 50 if frames < 1024 else 5, 5 if frames < 1024 else 1)
         _, gbs = saw_roofline(voices, frames, ms)
         vs = voices * frames / (ms * 1e-3)
         out.append({"workload": "saw bank, %d voices, %d frames/step" % (voices, frames),
                     "value": round(vs / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
                     "hbm_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "int_valu_frac": round(vs * 2.5 / 1e12 / INT_VALU_PEAK_TOPS, 4),
+                    # vector ops per voice-sample: 2.5 (direct) / 1.5 + 1 scalar (carry formulation)
+                    "formulation": "carry" if frames > 32 and voices * frames >= 1 << 31 else "direct",
+                    "int_valu_frac": round(vs * (1.5 if frames > 32 and voices * frames >= 1 << 31 else 2.5)
+                                           / 1e12 / INT_VALU_PEAK_TOPS, 4),
                     "max_voices_48k": int(vs / 48000)})
     # BASELINE config 2: 65 536 voices, 64-frame blocks
     inc, st = synthetic.saw_bank(65536, 0x5EED0002, tab)
