@@ -234,6 +234,10 @@ def main():
         bank.comm_init(rank, world, uid.cpu().numpy())
 
     comm = world > 1
+    if world == 1 and os.environ.get("SMX_BENCH_FORCE_COMM"):
+        # rehearsal of the multi-GPU code path on one GPU: 1-rank RCCL communicator
+        bank.comm_init(0, 1, sta.comm_unique_id())
+        comm = True
     for _ in range(a.warmup):
         bank.run_async(a.frames)
         if comm:
@@ -302,9 +306,10 @@ def main():
         if world == 1 and not a.no_also:
             line["also"] = also_workloads(sta, synthetic, tab, bank, a.voices)
         print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()          # every rank is done with its communicator before any is torn down
     bank.close()
     if dist:
-        dist.barrier()
         dist.destroy_process_group()
 
 
