@@ -201,7 +201,7 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
 
 extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
 {
-    if (n_voices == 0) { set_error("smx_bank_create: n_voices == 0"); return nullptr; }
+    if (n_voices == 0 || n_voices > 0xFFFFF000u) { set_error("smx_bank_create: n_voices=%u (1..2^32-4096)", n_voices); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("smx_bank_create: no HIP device (this library has no CPU fallback)");
@@ -576,7 +576,7 @@ extern "C" uint32_t pdm_safe_setpoint(uint32_t setpoint) { return setpoint; }  /
 
 extern "C" smx_pdm *smx_pdm_create(uint32_t n_channels, int device)
 {
-    if (n_channels == 0) { set_error("smx_pdm_create: n_channels == 0"); return nullptr; }
+    if (n_channels == 0 || n_channels > 0xFFFFF000u) { set_error("smx_pdm_create: n_channels=%u (1..2^32-4096)", n_channels); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("smx_pdm_create: no HIP device (this library has no CPU fallback)");
@@ -779,7 +779,7 @@ static void poly_slots(smx::PolyArrays &d, void **slots[12])
 
 extern "C" smx_poly *smx_poly_create(uint32_t n_voices, int device)
 {
-    if (n_voices == 0) { set_error("smx_poly_create: n_voices == 0"); return nullptr; }
+    if (n_voices == 0 || n_voices > 0xFFFFF000u) { set_error("smx_poly_create: n_voices=%u (1..2^32-4096)", n_voices); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("smx_poly_create: no HIP device (this library has no CPU fallback)");
@@ -921,7 +921,7 @@ static int pwm_slots(smx::PwmArrays &d, int order, void **slots[9])
 
 extern "C" smx_pwm *smx_pwm_create(uint32_t n_channels, int order, int device)
 {
-    if (n_channels == 0 || order < 1 || order > 4) {
+    if (n_channels == 0 || n_channels > 0xFFFFF000u || order < 1 || order > 4) {
         set_error("smx_pwm_create: n_channels=%u order=%d", n_channels, order);
         return nullptr;
     }
@@ -1151,7 +1151,7 @@ static int dev_reserve(void **ptr, size_t *cap, size_t need, hipStream_t stream)
 
 extern "C" smx_osc *smx_osc_create(uint32_t n, int device)
 {
-    if (n == 0) { set_error("smx_osc_create: n == 0"); return nullptr; }
+    if (n == 0 || n > 0xFFFFF000u) { set_error("smx_osc_create: n=%u (1..2^32-4096)", n); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("smx_osc_create: no HIP device (this library has no CPU fallback)");
@@ -1446,7 +1446,7 @@ struct smx_cproc {
 extern "C" smx_cproc *smx_cproc_create(uint32_t n_instances, const struct smx_cproc_node *nodes,
                                        uint32_t n_nodes, uint32_t n_inputs, int device)
 {
-    if (n_instances == 0 || !nodes || n_nodes == 0 || n_nodes > SMX_CPROC_MAX_NODES) {
+    if (n_instances == 0 || n_instances > 0xFFFFF000u || !nodes || n_nodes == 0 || n_nodes > SMX_CPROC_MAX_NODES) {
         set_error("smx_cproc_create: n_instances=%u n_nodes=%u (1..%d)", n_instances, n_nodes, SMX_CPROC_MAX_NODES);
         return nullptr;
     }

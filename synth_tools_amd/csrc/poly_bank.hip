@@ -49,18 +49,19 @@ void poly_bank_kernel(smx::PolyArrays p, int32_t *__restrict__ bus_lr, uint32_t 
             phase += inc;
             const float t = __fsub_rn(x, y);
             y = __fadd_rn(y, __fmul_rn(a, t));
-            if (stage == ENV_A) {
-                const uint32_t nl = level + ar;
-                if (nl < level) { level = 0xFFFFFFFFu; stage = ENV_D; } else level = nl;
-            } else if (stage == ENV_D) {
-                if (level <= sl || level - sl <= dr) { level = sl; stage = ENV_S; } else level -= dr;
-            } else if (stage == ENV_S) {
-                level = sl;
-            } else if (stage == ENV_R) {
-                if (level <= rr) { level = 0; stage = ENV_IDLE; } else level -= rr;
-            } else {
-                level = 0;
-            }
+            // ADSR stage machine, branch-free (lanes of a wave sit in different stages):
+            // every candidate is computed, the lane's stage selects one.
+            const uint32_t up = level + ar;                      // attack
+            const bool a_top = up < level;                       //   wrapped: reached the top
+            const bool d_done = (level <= sl) || (level - sl <= dr);   // decay reached sustain
+            const bool r_done = level <= rr;                     // release reached zero
+            uint32_t nl = 0, ns = ENV_IDLE;
+            if (stage == ENV_A) { nl = a_top ? 0xFFFFFFFFu : up;    ns = a_top ? ENV_D : ENV_A; }
+            if (stage == ENV_D) { nl = d_done ? sl : level - dr;    ns = d_done ? ENV_S : ENV_D; }
+            if (stage == ENV_S) { nl = sl;                          ns = ENV_S; }
+            if (stage == ENV_R) { nl = r_done ? 0u : level - rr;    ns = r_done ? ENV_IDLE : ENV_R; }
+            level = nl;
+            stage = ns;
             const float g = __fmul_rn((float)(level >> 8), 0x1p-24f);
             const float o = __fmul_rn(y, g);
             const int32_t q = (int32_t)__fmul_rn(o, 524288.0f);
