@@ -252,6 +252,21 @@ struct smx_pmeas_arrays {
 int smx_osc_load_pmeas(smx_osc *o, const struct smx_pmeas_arrays *a);
 int smx_osc_read_pmeas(smx_osc *o, const struct smx_pmeas_arrays *a);
 
+/* ---- clock bank: linux/clock.c:58-62, 106-120 ----------------------------- */
+/* N integer-divider square clocks.  Initial state as the reference: phase 0,
+ * polarity 1 (clock.c:61-62). */
+typedef struct smx_clock smx_clock;
+uint32_t smx_bpm_to_hperiod(uint32_t sample_rate, uint32_t bpm);    /* BPM_TO_HPERIOD, clock.c:58 */
+smx_clock *smx_clock_create(uint32_t n_clocks, int device);
+void smx_clock_destroy(smx_clock *c);
+int smx_clock_load(smx_clock *c, const uint32_t *hperiod, const int32_t *phase, const uint32_t *pol);
+int smx_clock_read(smx_clock *c, uint32_t *hperiod, int32_t *phase, uint32_t *pol);
+/* n_frames of the generator loop (clock.c:106-120).  pol_bits: the square wave
+ * (audio_out_buf[t] = clock_pol), tick_bits: the frames at which the reference sends
+ * MIDI clock 0xF8 (polarity turned 1).  Both host uint32[n_frames * ceil(n/32)],
+ * frame-major, clock c in bit c&31 of word c>>5; either may be NULL. */
+int smx_clock_run(smx_clock *c, uint32_t n_frames, uint32_t *pol_bits, uint32_t *tick_bits);
+
 /* ======================================================================== */
 /* 7. Firmware control surface, hosted: stm32f103/mod_synth.c:50-137 and the   */
 /*    packet entry stm32f103/synth.c:27-42                                     */

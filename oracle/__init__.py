@@ -76,6 +76,8 @@ def load():
     lib.orc_osc_event.argtypes = [C.POINTER(Pmeas), C.c_uint32]
     lib.orc_pwmosc_run.argtypes = [_u32p, _u32p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.orc_osc_bank_events.argtypes = [C.POINTER(Pmeas), C.c_uint32, _u32p, C.c_void_p, C.c_uint32]
+    lib.orc_bpm_to_hperiod.argtypes = [C.c_uint32, C.c_uint32]; lib.orc_bpm_to_hperiod.restype = C.c_uint32
+    lib.orc_clock_run.argtypes = [_u32p, _i32p, _u32p, C.c_uint32, C.c_uint32, _u32p, _u32p]
     lib.orc_acc_update.argtypes = [_u32p, C.c_uint32]
     lib.orc_edge_update.argtypes = [_u32p, _u32p, C.c_uint32]
     lib.orc_cproc_run.argtypes = [C.POINTER(CprocNode), C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p,

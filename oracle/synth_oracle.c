@@ -314,6 +314,29 @@ void orc_osc_bank_events(struct orc_pmeas *p, uint32_t n, const uint32_t *cc,
 }
 
 /* ======================================================================== */
+/* linux/clock.c                                                            */
+/* ======================================================================== */
+uint32_t orc_bpm_to_hperiod(uint32_t sr, uint32_t bpm) { return (sr * 5) / (bpm * 4); }   /* clock.c:58 */
+
+void orc_clock_run(const uint32_t *hperiod, int32_t *phase, uint32_t *pol, uint32_t n,
+                   uint32_t nframes, uint32_t *pol_bits, uint32_t *tick_bits) {
+    uint32_t words = (n + 31) >> 5;
+    memset(pol_bits, 0, (size_t)nframes * words * 4);
+    memset(tick_bits, 0, (size_t)nframes * words * 4);
+    for (uint32_t t = 0; t < nframes; t++)
+        for (uint32_t c = 0; c < n; c++) {
+            /* clock.c:108: `int clock_phase >= jack_nframes_t clock_hperiod` compares unsigned */
+            if ((uint32_t)phase[c] >= hperiod[c]) {
+                phase[c] -= (int32_t)hperiod[c];
+                pol[c] ^= 1;
+                if (pol[c] == 1) tick_bits[(size_t)t * words + (c >> 5)] |= 1u << (c & 31);
+            }
+            if (pol[c]) pol_bits[(size_t)t * words + (c >> 5)] |= 1u << (c & 31);
+            phase[c] += 1;
+        }
+}
+
+/* ======================================================================== */
 /* generic/cproc.h                                                          */
 /* ======================================================================== */
 void orc_acc_update(uint32_t *out, uint32_t in) { *out += in; }

@@ -111,6 +111,15 @@ void orc_pwmosc_run(uint32_t *phase, const uint32_t *speed, uint32_t n,
 void orc_osc_bank_events(struct orc_pmeas *p, uint32_t n, const uint32_t *cc,
                          const uint32_t *valid_bits, uint32_t nevents);
 
+/* ---- linux/clock.c ------------------------------------------------------- */
+/* N integer-divider square clocks (clock.c:106-120): per frame
+ *   if (phase >= hperiod) { phase -= hperiod; pol ^= 1; if (pol == 1) MIDI clock tick }
+ *   out = pol; phase += 1
+ * pol_bits / tick_bits: frame-major bit matrices (clock c -> bit c&31 of word c>>5). */
+uint32_t orc_bpm_to_hperiod(uint32_t sr, uint32_t bpm);      /* clock.c:58 */
+void orc_clock_run(const uint32_t *hperiod, int32_t *phase, uint32_t *pol, uint32_t n,
+                   uint32_t nframes, uint32_t *pol_bits, uint32_t *tick_bits);
+
 /* ---- generic/cproc.h ---------------------------------------------------- */
 void orc_acc_update(uint32_t *out, uint32_t in);                     /* :142-144 */
 void orc_edge_update(uint32_t *out, uint32_t *last, uint32_t in);    /* :152-155 */

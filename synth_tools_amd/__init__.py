@@ -142,6 +142,12 @@ ABI = [
     ("smx_osc_events", C.c_int, [_P, C.c_uint32, _P, _P]),
     ("smx_osc_load_pmeas", C.c_int, [_P, C.POINTER(PmeasArrays)]),
     ("smx_osc_read_pmeas", C.c_int, [_P, C.POINTER(PmeasArrays)]),
+    ("smx_bpm_to_hperiod", C.c_uint32, [C.c_uint32, C.c_uint32]),
+    ("smx_clock_create", _P, [C.c_uint32, C.c_int]),
+    ("smx_clock_destroy", None, [_P]),
+    ("smx_clock_load", C.c_int, [_P, _P, _P, _P]),
+    ("smx_clock_read", C.c_int, [_P, _P, _P, _P]),
+    ("smx_clock_run", C.c_int, [_P, C.c_uint32, _P, _P]),
     ("smx_cproc_create", _P, [C.c_uint32, C.POINTER(CprocNode), C.c_uint32, C.c_uint32, C.c_int]),
     ("smx_cproc_destroy", None, [_P]),
     ("smx_cproc_tick_n", C.c_int, [_P, C.c_uint32, _P, _P, C.c_uint32, _P]),
@@ -613,3 +619,37 @@ class CprocBank:
         st = np.empty((self.n_nodes, 2, self.n), np.uint32)
         _check(lib().smx_cproc_read_state(self._h, _ptr(st)), "smx_cproc_read_state")
         return st
+
+
+class ClockBank:
+    """N integer-divider square clocks / MIDI clock generators (linux/clock.c:106-120)."""
+
+    def __init__(self, n, device=0):
+        self._h = lib().smx_clock_create(n, device)
+        if not self._h:
+            raise SmxError("smx_clock_create: " + lib().smx_last_error().decode())
+        self.n, self.words = n, (n + 31) // 32
+
+    def close(self):
+        if self._h:
+            lib().smx_clock_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def load(self, hperiod=None, phase=None, pol=None):
+        hp = None if hperiod is None else np.ascontiguousarray(hperiod, np.uint32)
+        ph = None if phase is None else np.ascontiguousarray(phase, np.int32)
+        po = None if pol is None else np.ascontiguousarray(pol, np.uint32)
+        _check(lib().smx_clock_load(self._h, _ptr(hp), _ptr(ph), _ptr(po)), "smx_clock_load")
+
+    def read(self):
+        hp, ph, po = np.empty(self.n, np.uint32), np.empty(self.n, np.int32), np.empty(self.n, np.uint32)
+        _check(lib().smx_clock_read(self._h, _ptr(hp), _ptr(ph), _ptr(po)), "smx_clock_read")
+        return hp, ph, po
+
+    def run(self, n_frames):
+        pb = np.empty((n_frames, self.words), np.uint32)
+        tb = np.empty((n_frames, self.words), np.uint32)
+        _check(lib().smx_clock_run(self._h, n_frames, _ptr(pb), _ptr(tb)), "smx_clock_run")
+        return pb, tb

@@ -1545,3 +1545,103 @@ static int cproc_state_copy(smx_cproc *c, uint32_t *host, bool to_device)
 }
 extern "C" int smx_cproc_read_state(smx_cproc *c, uint32_t *state) { return cproc_state_copy(c, state, false); }
 extern "C" int smx_cproc_load_state(smx_cproc *c, const uint32_t *state) { return cproc_state_copy(c, (uint32_t *)state, true); }
+
+// ---------------------------------------------------------------------------
+// clock bank: linux/clock.c:58-62, 106-120
+// ---------------------------------------------------------------------------
+struct smx_clock {
+    uint32_t n = 0, n_pad = 0;
+    int device = 0;
+    uint32_t *d_hperiod = nullptr, *d_phase = nullptr, *d_pol = nullptr;
+    void *d_pbits = nullptr; size_t pbits_cap = 0;
+    void *d_tbits = nullptr; size_t tbits_cap = 0;
+    hipStream_t stream = nullptr;
+};
+
+extern "C" uint32_t smx_bpm_to_hperiod(uint32_t sr, uint32_t bpm) { return bpm ? (sr * 5) / (bpm * 4) : 0; }
+
+extern "C" smx_clock *smx_clock_create(uint32_t n, int device)
+{
+    if (n == 0 || n > 0xFFFFF000u) { set_error("smx_clock_create: n=%u", n); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("smx_clock_create: no HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { set_error("smx_clock_create: device %d of %d", device, ndev); return nullptr; }
+    smx_clock *c = new smx_clock();
+    c->n = n;
+    c->n_pad = smx::round_up(n, 1024);
+    c->device = device;
+    const size_t bytes = (size_t)c->n_pad * 4;
+    std::vector<uint32_t> ones(c->n_pad, 1u);                      // clock_pol = 1, clock.c:62
+    bool ok = hipSetDevice(device) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void **)&c->d_hperiod, bytes) == hipSuccess &&
+              hipMalloc((void **)&c->d_phase, bytes) == hipSuccess &&
+              hipMalloc((void **)&c->d_pol, bytes) == hipSuccess &&
+              hipMemset(c->d_hperiod, 0, bytes) == hipSuccess && hipMemset(c->d_phase, 0, bytes) == hipSuccess &&
+              hipMemcpy(c->d_pol, ones.data(), bytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        set_error("smx_clock_create: HIP allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        smx_clock_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void smx_clock_destroy(smx_clock *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_hperiod) (void)hipFree(c->d_hperiod);
+    if (c->d_phase) (void)hipFree(c->d_phase);
+    if (c->d_pol) (void)hipFree(c->d_pol);
+    if (c->d_pbits) (void)hipFree(c->d_pbits);
+    if (c->d_tbits) (void)hipFree(c->d_tbits);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int smx_clock_load(smx_clock *c, const uint32_t *hperiod, const int32_t *phase, const uint32_t *pol)
+{
+    if (!c) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(c->device));
+    SMX_HIP(hipStreamSynchronize(c->stream));
+    if (hperiod) SMX_HIP(hipMemcpy(c->d_hperiod, hperiod, (size_t)c->n * 4, hipMemcpyHostToDevice));
+    if (phase) SMX_HIP(hipMemcpy(c->d_phase, phase, (size_t)c->n * 4, hipMemcpyHostToDevice));
+    if (pol) SMX_HIP(hipMemcpy(c->d_pol, pol, (size_t)c->n * 4, hipMemcpyHostToDevice));
+    return SMX_OK;
+}
+
+extern "C" int smx_clock_read(smx_clock *c, uint32_t *hperiod, int32_t *phase, uint32_t *pol)
+{
+    if (!c) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(c->device));
+    SMX_HIP(hipStreamSynchronize(c->stream));
+    if (hperiod) SMX_HIP(hipMemcpy(hperiod, c->d_hperiod, (size_t)c->n * 4, hipMemcpyDeviceToHost));
+    if (phase) SMX_HIP(hipMemcpy(phase, c->d_phase, (size_t)c->n * 4, hipMemcpyDeviceToHost));
+    if (pol) SMX_HIP(hipMemcpy(pol, c->d_pol, (size_t)c->n * 4, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+extern "C" int smx_clock_run(smx_clock *c, uint32_t n_frames, uint32_t *pol_bits, uint32_t *tick_bits)
+{
+    if (!c) return SMX_E_ARG;
+    if (n_frames == 0) return SMX_OK;
+    SMX_HIP(hipSetDevice(c->device));
+    const size_t row = (size_t)c->n_pad / 8, words = (c->n + 31) / 32;
+    int rv;
+    if ((rv = dev_reserve(&c->d_pbits, &c->pbits_cap, (size_t)n_frames * row, c->stream))) return rv;
+    if ((rv = dev_reserve(&c->d_tbits, &c->tbits_cap, (size_t)n_frames * row, c->stream))) return rv;
+    rv = smx::launch_clock(c->d_hperiod, c->d_phase, c->d_pol, (uint32_t *)c->d_pbits, (uint32_t *)c->d_tbits,
+                           c->n_pad, c->n, n_frames, c->stream);
+    if (rv) return rv;
+    if (pol_bits)
+        SMX_HIP(hipMemcpy2DAsync(pol_bits, words * 4, c->d_pbits, row, words * 4, n_frames, hipMemcpyDeviceToHost, c->stream));
+    if (tick_bits)
+        SMX_HIP(hipMemcpy2DAsync(tick_bits, words * 4, c->d_tbits, row, words * 4, n_frames, hipMemcpyDeviceToHost, c->stream));
+    SMX_HIP(hipStreamSynchronize(c->stream));
+    return SMX_OK;
+}

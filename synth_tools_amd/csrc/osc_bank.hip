@@ -86,9 +86,63 @@ void osc_events_kernel(smx::PmeasArrays p, const uint32_t *__restrict__ cc,
     p.avg0[c] = avg[0]; p.avg1[c] = avg[1]; p.num0[c] = npub[0]; p.num1[c] = npub[1];
 }
 
+// (3) clock bank: the integer-divider square wave / MIDI clock of linux/clock.c:106-120,
+//     N dividers.  One lane per clock; the wave's 64 polarity bits of a frame are the
+//     compare mask, collected per lane (lane t keeps frame t) and transposed through LDS
+//     into frame-major bit matrices like the PDM bank's pulses.
+__global__ __launch_bounds__(256)
+void clock_kernel(const uint32_t *__restrict__ hperiod, uint32_t *__restrict__ phase,
+                  uint32_t *__restrict__ pol, unsigned long long *__restrict__ pol_bits,
+                  unsigned long long *__restrict__ tick_bits, uint32_t words64_per_row,
+                  uint32_t n, uint32_t nframes)
+{
+    __shared__ unsigned long long S[2][64][5];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = blockIdx.x * 256u + tid;
+    const bool live = c < n;
+    const uint32_t hp = live ? hperiod[c] : 0xFFFFFFFFu;
+    uint32_t ph = live ? phase[c] : 0u, po = live ? pol[c] : 0u;
+    for (uint32_t t0 = 0; t0 < nframes; t0 += 64) {
+        const uint32_t nt = min(64u, nframes - t0);
+        unsigned long long wp = 0, wt = 0;
+        for (uint32_t t = 0; t < nt; t++) {
+            const bool roll = live && ph >= hp;              // clock.c:108 (unsigned compare)
+            if (roll) { ph -= hp; po ^= 1u; }
+            const unsigned long long mp = __ballot(po != 0);
+            const unsigned long long mt = __ballot(roll && po == 1u);   // positive edge: MIDI clock 0xF8
+            if (lane == t) { wp = mp; wt = mt; }
+            ph += 1;
+        }
+        S[0][lane][wave] = wp;
+        S[1][lane][wave] = wt;
+        __syncthreads();
+        // 64 rows x 4 words: one thread per (row, word)
+        const uint32_t row = tid >> 2, col = tid & 3;
+        if (row < nt) {
+            const size_t o = (size_t)(t0 + row) * words64_per_row + blockIdx.x * 4u + col;
+            pol_bits[o] = S[0][row][col];
+            tick_bits[o] = S[1][row][col];
+        }
+        __syncthreads();
+    }
+    if (live) { phase[c] = ph; pol[c] = po; }
+}
+
 }  // namespace
 
 namespace smx {
+
+int launch_clock(const uint32_t *d_hperiod, uint32_t *d_phase, uint32_t *d_pol, uint32_t *d_pol_bits,
+                 uint32_t *d_tick_bits, uint32_t n_pad, uint32_t n, uint32_t nframes, hipStream_t stream)
+{
+    if (n_pad == 0 || (n_pad & 1023) || n > n_pad) { set_error("launch_clock: n_pad=%u n=%u", n_pad, n); return SMX_E_ARG; }
+    if (nframes == 0) return SMX_OK;
+    hipLaunchKernelGGL(clock_kernel, dim3(n_pad / 256), dim3(256), 0, stream, d_hperiod, d_phase, d_pol,
+                       reinterpret_cast<unsigned long long *>(d_pol_bits),
+                       reinterpret_cast<unsigned long long *>(d_tick_bits), n_pad / 64, n, nframes);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
 
 int launch_pwmosc(uint32_t *d_phase, const uint32_t *d_speed, const uint32_t *d_sync_bits,
                   uint8_t *d_duty, uint32_t n_pad, uint32_t nticks, hipStream_t stream)

@@ -81,6 +81,9 @@ int launch_pwmosc(uint32_t *d_phase, const uint32_t *d_speed, const uint32_t *d_
 int launch_osc_events(const PmeasArrays &p, const uint32_t *d_cc, const uint32_t *d_valid_bits,
                       uint32_t n, uint32_t nevents, uint32_t log_max, hipStream_t stream);
 
+int launch_clock(const uint32_t *d_hperiod, uint32_t *d_phase, uint32_t *d_pol, uint32_t *d_pol_bits,
+                 uint32_t *d_tick_bits, uint32_t n_pad, uint32_t n, uint32_t nframes, hipStream_t stream);
+
 // cproc dataflow bank (cproc_bank.hip)
 #define SMX_CPROC_MAX_NODES 32
 struct CprocNode { uint32_t proc, in, cond; };

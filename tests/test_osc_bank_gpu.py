@@ -90,3 +90,29 @@ def test_osc_events_parity(smx, orc, n):
         assert got[k].tolist() == v, k
     assert max(want["write"]) >= 2          # averages were published
     bank.close()
+
+
+@pytest.mark.parametrize("n", [1, 33, 1500])
+def test_clock_bank_parity(smx, orc, n):
+    """linux/clock.c:106-120 square-wave / MIDI-clock dividers, incl. hperiod 0 (toggles every
+    frame) and the reference's operating point (120 bpm @ 48 kHz -> hperiod 500)."""
+    assert smx.lib().smx_bpm_to_hperiod(48000, 120) == orc.orc_bpm_to_hperiod(48000, 120) == 500
+    rng = np.random.default_rng(n)
+    hp = rng.integers(0, 300, n).astype(np.uint32)
+    hp[0] = 500
+    if n > 2:
+        hp[1], hp[2] = 0, 1
+    bank = smx.ClockBank(n)
+    _, ph0, po0 = bank.read()
+    assert np.all(ph0 == 0) and np.all(po0 == 1)            # clock.c:61-62
+    bank.load(hperiod=hp)
+    ph, po = np.zeros(n, np.int32), np.ones(n, np.uint32)
+    words = (n + 31) // 32
+    for nf in (1, 63, 64, 65, 700):
+        gp, gt = bank.run(nf)
+        wp, wt = np.zeros(nf * words, np.uint32), np.zeros(nf * words, np.uint32)
+        orc.orc_clock_run(hp, ph, po, n, nf, wp, wt)
+        assert np.array_equal(gp.reshape(-1), wp) and np.array_equal(gt.reshape(-1), wt)
+    ghp, gph, gpo = bank.read()
+    assert np.array_equal(gph, ph) and np.array_equal(gpo, po) and np.array_equal(ghp, hp)
+    bank.close()
