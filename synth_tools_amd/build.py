@@ -6,8 +6,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsynth_mi355x.so")
-SOURCES = ["saw_bank.hip", "pdm_bank.hip", "poly_bank.hip", "pwm_bank.hip", "osc_bank.hip", "cproc_bank.hip", "abi.cpp"]
-HEADERS = ["smx_common.h", os.path.join("..", "..", "include", "synth_mi355x.h")]
+SOURCES = ["saw_bank.hip", "pdm_bank.hip", "poly_bank.hip", "pwm_bank.hip", "osc_bank.hip", "cproc_bank.hip",
+           "abi_core.cpp", "abi_saw.cpp", "abi_pdm.cpp", "abi_pwm.cpp", "abi_poly.cpp", "abi_osc.cpp",
+           "abi_cproc.cpp", "abi_fw.cpp"]
+HEADERS = ["smx_common.h", "abi_internal.h", os.path.join("..", "..", "include", "synth_mi355x.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-result"]
 

@@ -1,0 +1,431 @@
+// abi_saw.cpp -- part of the C-ABI of libsynth_mi355x.so (include/synth_mi355x.h): saw voice bank, note allocator over N voices, RCCL bus sum
+// Host side of the drop-in boundary.  No CPU compute fallback exists: every compute entry
+// point needs a HIP device and fails with SMX_E_NOGPU otherwise.
+#include "abi_internal.h"
+#include <rccl/rccl.h>
+
+namespace smx {
+
+// First-free search over N voices in O(log64 N): the reference scans its 64
+// voices linearly (linux/synth.c:147-149); a bank has up to 2^32.
+class FreeMap {
+public:
+    void reset(uint32_t n, bool all_free)
+    {
+        n_ = n;
+        levels_.clear();
+        uint32_t bits = n;
+        do {
+            uint32_t words = (bits + 63) / 64;
+            levels_.emplace_back(words, 0ull);
+            bits = words;
+        } while (bits > 1);
+        if (all_free)
+            for (uint32_t v = 0; v < n; v++) set_leaf_only(v);
+        rebuild_summaries();
+    }
+    void load(const uint32_t *inc, uint32_t n)
+    {
+        reset(n, false);
+        for (uint32_t v = 0; v < n; v++)
+            if (inc[v] == 0) set_leaf_only(v);
+        rebuild_summaries();
+    }
+    void set_free(uint32_t v, bool is_free)
+    {
+        uint32_t idx = v;
+        for (size_t l = 0; l < levels_.size(); l++) {
+            uint64_t &w = levels_[l][idx >> 6];
+            const uint64_t bit = 1ull << (idx & 63);
+            if (is_free) w |= bit; else w &= ~bit;
+            const bool any = w != 0;
+            idx >>= 6;
+            if (l + 1 < levels_.size()) {
+                const bool was = (levels_[l + 1][idx >> 6] >> (idx & 63)) & 1;
+                if (was == any) break;
+                is_free = any;
+            }
+        }
+    }
+    // index of the first free voice, or -1
+    int64_t first_free() const
+    {
+        if (levels_.empty() || levels_.back()[0] == 0) return -1;
+        uint32_t idx = 0;
+        for (size_t l = levels_.size(); l-- > 0;) {
+            const uint64_t w = levels_[l][idx];
+            idx = idx * 64 + (uint32_t)__builtin_ctzll(w);
+        }
+        return idx < n_ ? (int64_t)idx : -1;
+    }
+private:
+    void set_leaf_only(uint32_t v) { levels_[0][v >> 6] |= 1ull << (v & 63); }
+    void rebuild_summaries()
+    {
+        for (size_t l = 1; l < levels_.size(); l++) {
+            std::fill(levels_[l].begin(), levels_[l].end(), 0ull);
+            for (size_t i = 0; i < levels_[l - 1].size(); i++)
+                if (levels_[l - 1][i]) levels_[l][i >> 6] |= 1ull << (i & 63);
+        }
+    }
+    uint32_t n_ = 0;
+    std::vector<std::vector<uint64_t>> levels_;
+};
+
+}  // namespace smx
+
+// ---------------------------------------------------------------------------
+// saw bank
+// ---------------------------------------------------------------------------
+struct smx_bank {
+    uint32_t n = 0, n_pad = 0;
+    int device = 0;
+    uint32_t *d_inc = nullptr;
+    uint32_t *d_state[2] = {nullptr, nullptr};   // ping-pong (saw_bank.hip)
+    int cur = 0;
+    // three bus buffers in rotation: [cur] holds the last block (and may be feeding an
+    // all-reduce), [cur+1] was zeroed by the last launch for the next one, [cur+2] is
+    // the one the next launch will zero.
+    static constexpr int NBUS = 3;
+    int32_t *d_bus[NBUS] = {nullptr, nullptr, nullptr};
+    uint32_t bus_zeroed[NBUS] = {0, 0, 0};       // leading frames known to be zero
+    int bus_cur = 0;
+    uint32_t bus_cap = 0;
+    int32_t *h_bus = nullptr;                    // pinned
+    void *d_scratch = nullptr;                   // partial sums of saw_bank.hip's carry formulation
+    hipStream_t stream = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_kernel[NBUS] = {nullptr, nullptr, nullptr};   // kernel of bus[i] finished
+    hipEvent_t ev_comm[NBUS] = {nullptr, nullptr, nullptr};     // all-reduce of bus[i] finished
+    bool comm_pending[NBUS] = {false, false, false};
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    int note2voice[128];
+    smx::FreeMap free_map;
+};
+
+static int bank_ensure_bus(smx_bank *b, uint32_t n)
+{
+    if (n <= b->bus_cap) return SMX_OK;
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
+    const uint32_t cap = smx::round_up(n < 4096 ? 4096 : n, 4096);
+    for (int i = 0; i < smx_bank::NBUS; i++) {
+        if (b->d_bus[i]) SMX_HIP(hipFree(b->d_bus[i]));
+        b->d_bus[i] = nullptr;
+        SMX_HIP(hipMalloc((void **)&b->d_bus[i], (size_t)cap * 4));
+        SMX_HIP(hipMemset(b->d_bus[i], 0, (size_t)cap * 4));
+        b->bus_zeroed[i] = cap;
+        b->comm_pending[i] = false;
+    }
+    if (b->h_bus) SMX_HIP(hipHostFree(b->h_bus));
+    b->h_bus = nullptr;
+    SMX_HIP(hipHostMalloc((void **)&b->h_bus, (size_t)cap * 4, hipHostMallocDefault));
+    if (b->d_scratch) SMX_HIP(hipFree(b->d_scratch));
+    b->d_scratch = nullptr;
+    if (b->n_pad >= (1u << 20)) {
+        SMX_HIP(hipMalloc(&b->d_scratch, smx::saw_scratch_bytes(cap)));
+        SMX_HIP(hipMemset(b->d_scratch, 0, smx::saw_scratch_bytes(cap)));   // slots are kept zero between launches
+    }
+    b->bus_cap = cap;
+    return SMX_OK;
+}
+
+extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
+{
+    if (n_voices == 0 || n_voices > 0xFFFFF000u) { set_error("smx_bank_create: n_voices=%u (1..2^32-4096)", n_voices); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("smx_bank_create: no HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { set_error("smx_bank_create: device %d of %d", device, ndev); return nullptr; }
+    smx_bank *b = new smx_bank();
+    b->n = n_voices;
+    b->n_pad = smx::round_up(n_voices, 1024);
+    b->device = device;
+    auto fail = [&](const char *what, hipError_t e) -> smx_bank * {
+        set_error("smx_bank_create: %s: %s", what, hipGetErrorString(e));
+        smx_bank_destroy(b);
+        return nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    const size_t bytes = (size_t)b->n_pad * 4;
+    if ((e = hipMalloc((void **)&b->d_inc, bytes)) != hipSuccess) return fail("hipMalloc inc", e);
+    for (int i = 0; i < 2; i++)
+        if ((e = hipMalloc((void **)&b->d_state[i], bytes)) != hipSuccess) return fail("hipMalloc state", e);
+    if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+    if ((e = hipEventCreate(&b->ev_t0)) != hipSuccess) return fail("event", e);
+    if ((e = hipEventCreate(&b->ev_t1)) != hipSuccess) return fail("event", e);
+    for (int i = 0; i < smx_bank::NBUS; i++) {
+        if ((e = hipEventCreateWithFlags(&b->ev_kernel[i], hipEventDisableTiming)) != hipSuccess) return fail("event", e);
+        if ((e = hipEventCreateWithFlags(&b->ev_comm[i], hipEventDisableTiming)) != hipSuccess) return fail("event", e);
+    }
+    // synth_init: bzero (linux/synth.c:204-206); padding voices stay off forever
+    if ((e = hipMemsetAsync(b->d_inc, 0, bytes, b->stream)) != hipSuccess) return fail("memset", e);
+    for (int i = 0; i < 2; i++)
+        if ((e = hipMemsetAsync(b->d_state[i], 0, bytes, b->stream)) != hipSuccess) return fail("memset", e);
+    if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return fail("sync", e);
+    memset(b->note2voice, 0, sizeof(b->note2voice));
+    b->free_map.reset(b->n, true);
+    if (bank_ensure_bus(b, 4096) != SMX_OK) { smx_bank_destroy(b); return nullptr; }
+    return b;
+}
+
+extern "C" void smx_bank_destroy(smx_bank *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->comm_stream) (void)hipStreamSynchronize(b->comm_stream);
+    if (b->comm) (void)ncclCommDestroy(b->comm);
+    if (b->d_inc) (void)hipFree(b->d_inc);
+    for (int i = 0; i < 2; i++)
+        if (b->d_state[i]) (void)hipFree(b->d_state[i]);
+    for (int i = 0; i < smx_bank::NBUS; i++) {
+        if (b->d_bus[i]) (void)hipFree(b->d_bus[i]);
+        if (b->ev_kernel[i]) (void)hipEventDestroy(b->ev_kernel[i]);
+        if (b->ev_comm[i]) (void)hipEventDestroy(b->ev_comm[i]);
+    }
+    if (b->h_bus) (void)hipHostFree(b->h_bus);
+    if (b->d_scratch) (void)hipFree(b->d_scratch);
+    if (b->ev_t0) (void)hipEventDestroy(b->ev_t0);
+    if (b->ev_t1) (void)hipEventDestroy(b->ev_t1);
+    if (b->comm_stream) (void)hipStreamDestroy(b->comm_stream);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+extern "C" uint32_t smx_bank_voices(const smx_bank *b) { return b ? b->n : 0; }
+
+extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *state)
+{
+    if (!b) { set_error("smx_bank_load: null bank"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (inc) {
+        SMX_HIP(hipMemcpy(b->d_inc, inc, (size_t)b->n * 4, hipMemcpyHostToDevice));
+        b->free_map.load(inc, b->n);
+    }
+    if (state)
+        SMX_HIP(hipMemcpy(b->d_state[b->cur], state, (size_t)b->n * 4, hipMemcpyHostToDevice));
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state)
+{
+    if (!b) { set_error("smx_bank_read: null bank"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (inc) SMX_HIP(hipMemcpy(inc, b->d_inc, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    if (state) SMX_HIP(hipMemcpy(state, b->d_state[b->cur], (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+static int bank_set_inc(smx_bank *b, uint32_t v, uint32_t inc)
+{
+    SMX_HIP(hipSetDevice(b->device));
+    // pageable 4-byte source: hipMemcpyAsync stages it before returning
+    SMX_HIP(hipMemcpyAsync(b->d_inc + v, &inc, 4, hipMemcpyHostToDevice, b->stream));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    b->free_map.set_free(v, inc == 0);
+    return SMX_OK;
+}
+
+// linux/synth.c:156-160 over N voices
+extern "C" int smx_bank_note_on(smx_bank *b, int note)
+{
+    if (!b) { set_error("smx_bank_note_on: null bank"); return SMX_E_ARG; }
+    if (note < 0) { set_error("smx_bank_note_on: note %d < 0", note); return SMX_E_ARG; }
+    int64_t v = b->free_map.first_free();
+    if (v < 0) v = 0;                                  // steal voice 0 (:150-153)
+    b->note2voice[note % 128] = (int)v;
+    return bank_set_inc(b, (uint32_t)v, note_to_inc(note % 128));
+}
+
+// linux/synth.c:161-165 over N voices
+extern "C" int smx_bank_note_off(smx_bank *b, int note)
+{
+    if (!b) { set_error("smx_bank_note_off: null bank"); return SMX_E_ARG; }
+    if (note < 0) { set_error("smx_bank_note_off: note %d < 0", note); return SMX_E_ARG; }
+    const int v = b->note2voice[note % 128];
+    b->note2voice[note % 128] = 0;
+    return bank_set_inc(b, (uint32_t)v, 0);
+}
+
+// Wait (on the compute stream) until nothing in flight still uses bus buffer i.
+static int bank_bus_release(smx_bank *b, int i)
+{
+    if (b->comm_pending[i]) {
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[i], 0));
+        b->comm_pending[i] = false;
+    }
+    return SMX_OK;
+}
+
+// Rotate to the next bus buffer and make sure its first n frames are zero.
+static int bank_bus_advance(smx_bank *b, uint32_t n, int *bi_out, int *bnext_out)
+{
+    const int bi = (b->bus_cur + 1) % smx_bank::NBUS;
+    const int bnext = (bi + 1) % smx_bank::NBUS;
+    int rv = bank_bus_release(b, bi);
+    if (rv) return rv;
+    rv = bank_bus_release(b, bnext);      // the launch is about to zero it
+    if (rv) return rv;
+    if (b->bus_zeroed[bi] < n) {
+        SMX_HIP(hipMemsetAsync(b->d_bus[bi], 0, (size_t)n * 4, b->stream));
+        b->bus_zeroed[bi] = n;
+    }
+    *bi_out = bi;
+    *bnext_out = bnext;
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_run_async(smx_bank *b, int n)
+{
+    if (!b || n <= 0) { set_error("smx_bank_run_async: bad args"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    int rv = bank_ensure_bus(b, (uint32_t)n);
+    if (rv) return rv;
+    int bi, bnext;
+    rv = bank_bus_advance(b, (uint32_t)n, &bi, &bnext);
+    if (rv) return rv;
+    rv = smx::launch_saw_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1], b->d_bus[bi],
+                              b->d_bus[bnext], b->n_pad, (uint32_t)n, b->d_scratch, b->stream);
+    if (rv) return rv;
+    b->bus_zeroed[bi] = 0;                 // now holds this block's sums
+    b->bus_zeroed[bnext] = (uint32_t)n;    // cleared by the launch
+    b->cur ^= 1;
+    b->bus_cur = bi;
+    return SMX_OK;
+}
+
+extern "C" void *smx_bank_bus_dev(smx_bank *b) { return b ? b->d_bus[b->bus_cur] : nullptr; }
+
+extern "C" int smx_bank_sync(smx_bank *b)
+{
+    if (!b) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
+{
+    if (!b || n <= 0 || (uint32_t)n > b->bus_cap) { set_error("smx_bank_fetch: bad args"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    const int bi = b->bus_cur;
+    if (b->comm_pending[bi]) {
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
+        b->comm_pending[bi] = false;
+    }
+    SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (bus) memcpy(bus, b->h_bus, (size_t)n * 4);
+    if (vec) for (int i = 0; i < n; i++) vec[i] = bus_to_float(b->h_bus[i]);
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_run(smx_bank *b, float *vec, int32_t *bus, int n)
+{
+    int rv = smx_bank_run_async(b, n);
+    if (rv) return rv;
+    return smx_bank_fetch(b, vec, bus, n);
+}
+
+extern "C" int smx_bank_run_square(smx_bank *b, float *vec, int n)
+{
+    if (!b || n <= 0) { set_error("smx_bank_run_square: bad args"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    int rv = bank_ensure_bus(b, (uint32_t)n);
+    if (rv) return rv;
+    const int bi = (b->bus_cur + 1) % smx_bank::NBUS;
+    rv = bank_bus_release(b, bi);
+    if (rv) return rv;
+    SMX_HIP(hipMemsetAsync(b->d_bus[bi], 0, (size_t)n * 4, b->stream));
+    b->bus_zeroed[bi] = 0;
+    rv = smx::launch_square_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1],
+                                 (uint32_t *)b->d_bus[bi], b->n_pad, (uint32_t)n, b->stream);
+    if (rv) return rv;
+    b->cur ^= 1;
+    b->bus_cur = bi;
+    SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    // linux/synth.c:194: (1.0 / 2^32) * (float)accu, accu unsigned
+    if (vec)
+        for (int i = 0; i < n; i++)
+            vec[i] = (float)((1.0 / 4294967296.0) * (double)(float)(uint32_t)b->h_bus[i]);
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_timer_start(smx_bank *b)
+{
+    if (!b) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipEventRecord(b->ev_t0, b->stream));
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_timer_stop(smx_bank *b, float *ms)
+{
+    if (!b || !ms) return SMX_E_ARG;
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipEventRecord(b->ev_t1, b->stream));
+    SMX_HIP(hipEventSynchronize(b->ev_t1));
+    SMX_HIP(hipEventElapsedTime(ms, b->ev_t0, b->ev_t1));
+    return SMX_OK;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------
+#define SMX_NCCL(expr)                                                         \
+    do {                                                                       \
+        ncclResult_t r_ = (expr);                                              \
+        if (r_ != ncclSuccess) {                                               \
+            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
+                      ncclGetErrorString(r_));                                 \
+            return SMX_E_COMM;                                                 \
+        }                                                                      \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == SMX_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+extern "C" int smx_comm_unique_id(uint8_t id[SMX_UNIQUE_ID_BYTES])
+{
+    ncclUniqueId u;
+    SMX_NCCL(ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_comm_init(smx_bank *b, int rank, int nranks,
+                                  const uint8_t id[SMX_UNIQUE_ID_BYTES])
+{
+    if (!b || nranks < 1 || rank < 0 || rank >= nranks) { set_error("smx_bank_comm_init: bad args"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    SMX_NCCL(ncclCommInitRank(&b->comm, nranks, u, rank));
+    SMX_HIP(hipStreamCreateWithFlags(&b->comm_stream, hipStreamNonBlocking));
+    b->rank = rank;
+    b->nranks = nranks;
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_allreduce_async(smx_bank *b, int n)
+{
+    if (!b || n <= 0 || (uint32_t)n > b->bus_cap) { set_error("smx_bank_allreduce_async: bad args"); return SMX_E_ARG; }
+    if (!b->comm) { set_error("smx_bank_allreduce_async: smx_bank_comm_init not called"); return SMX_E_STATE; }
+    SMX_HIP(hipSetDevice(b->device));
+    const int bi = b->bus_cur;
+    SMX_HIP(hipEventRecord(b->ev_kernel[bi], b->stream));
+    SMX_HIP(hipStreamWaitEvent(b->comm_stream, b->ev_kernel[bi], 0));
+    // integer sum: associative, so the result is the same bits in any order
+    SMX_NCCL(ncclAllReduce(b->d_bus[bi], b->d_bus[bi], (size_t)n, ncclInt32, ncclSum, b->comm,
+                           b->comm_stream));
+    SMX_HIP(hipEventRecord(b->ev_comm[bi], b->comm_stream));
+    b->comm_pending[bi] = true;
+    return SMX_OK;
+}
+
