@@ -85,14 +85,8 @@ static inline void process_midi(jack_nframes_t nframes) {        /* linux/synth.
         jack_midi_event_t event;
         jack.midi_event_get(&event, midi_in_buf, i);
         const uint8_t *msg = event.buffer;
-        if (!bank) { synth_midi_event(&synth, msg, event.size); continue; }
-        if (event.size != 3) continue;
-        if (msg[0] == 0x90) {
-            if (msg[2] == 0) ASSERT(0 == smx_bank_note_off(bank, msg[1]));
-            else             ASSERT(0 == smx_bank_note_on(bank, msg[1]));
-        } else if (msg[0] == 0x80) {
-            ASSERT(0 == smx_bank_note_off(bank, msg[1]));
-        }
+        if (bank) ASSERT(0 == smx_bank_midi_event(bank, msg, event.size));
+        else      synth_midi_event(&synth, msg, event.size);
     }
 }
 static inline void process_audio(jack_nframes_t nframes) {       /* linux/synth.c:261-276 */

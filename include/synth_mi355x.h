@@ -86,6 +86,9 @@ int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state);
  * never-played note silences voice 0 (linux/synth.c:145-165). */
 int smx_bank_note_on (smx_bank *b, int note);
 int smx_bank_note_off(smx_bank *b, int note);
+/* MIDI dispatch of process_midi (linux/synth.c:236-258) for one event; the updates
+ * are queued on the bank's stream ahead of the next block, without a host sync. */
+int smx_bank_midi_event(smx_bank *b, const uint8_t *msg, size_t size);
 
 /* synth_run over the bank (linux/synth.c:196-202).  vec: host float[n] or
  * NULL; bus: host int32[n] or NULL (the integer sum before the 2^-32 scale,

@@ -83,6 +83,7 @@ ABI = [
     ("smx_bank_read", C.c_int, [_P, _P, _P]),
     ("smx_bank_note_on", C.c_int, [_P, C.c_int]),
     ("smx_bank_note_off", C.c_int, [_P, C.c_int]),
+    ("smx_bank_midi_event", C.c_int, [_P, _u8, C.c_size_t]),
     ("smx_bank_run", C.c_int, [_P, _P, _P, C.c_int]),
     ("smx_bank_run_async", C.c_int, [_P, C.c_int]),
     ("smx_bank_bus_dev", _P, [_P]),
@@ -229,6 +230,10 @@ class SawBank:
 
     def note_off(self, note):
         _check(lib().smx_bank_note_off(self._h, note), "smx_bank_note_off")
+
+    def midi_event(self, msg):
+        m = np.ascontiguousarray(msg, np.uint8)
+        _check(lib().smx_bank_midi_event(self._h, m, len(m)), "smx_bank_midi_event")
 
     def run(self, n):
         """synth_run for n frames -> (bus int32[n], vec float32[n])."""

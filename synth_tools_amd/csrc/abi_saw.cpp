@@ -92,6 +92,9 @@ struct smx_bank {
     int bus_cur = 0;
     uint32_t bus_cap = 0;
     int32_t *h_bus = nullptr;                    // pinned
+    uint32_t *h_stage = nullptr;                 // pinned ring of pending inc[] updates (note on/off)
+    uint32_t stage_pos = 0;
+    static constexpr uint32_t STAGE_SLOTS = 4096;
     void *d_scratch = nullptr;                   // partial sums of saw_bank.hip's carry formulation
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
@@ -169,6 +172,8 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return fail("sync", e);
     memset(b->note2voice, 0, sizeof(b->note2voice));
     b->free_map.reset(b->n, true);
+    if ((e = hipHostMalloc((void **)&b->h_stage, smx_bank::STAGE_SLOTS * 4, hipHostMallocDefault)) != hipSuccess)
+        return fail("hipHostMalloc", e);
     if (bank_ensure_bus(b, 4096) != SMX_OK) { smx_bank_destroy(b); return nullptr; }
     return b;
 }
@@ -189,6 +194,7 @@ extern "C" void smx_bank_destroy(smx_bank *b)
         if (b->ev_comm[i]) (void)hipEventDestroy(b->ev_comm[i]);
     }
     if (b->h_bus) (void)hipHostFree(b->h_bus);
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
     if (b->ev_t0) (void)hipEventDestroy(b->ev_t0);
     if (b->ev_t1) (void)hipEventDestroy(b->ev_t1);
@@ -204,6 +210,7 @@ extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *s
     if (!b) { set_error("smx_bank_load: null bank"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
     SMX_HIP(hipStreamSynchronize(b->stream));
+    b->stage_pos = 0;
     if (inc) {
         SMX_HIP(hipMemcpy(b->d_inc, inc, (size_t)b->n * 4, hipMemcpyHostToDevice));
         b->free_map.load(inc, b->n);
@@ -223,12 +230,19 @@ extern "C" int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state)
     return SMX_OK;
 }
 
+// One voice's increment changes: a 4-byte async copy from a pinned ring slot, ordered on the
+// bank's stream before the next block's kernel.  No host sync per event: the JACK thread can
+// apply a burst of MIDI events and launch the block right behind them.
 static int bank_set_inc(smx_bank *b, uint32_t v, uint32_t inc)
 {
     SMX_HIP(hipSetDevice(b->device));
-    // pageable 4-byte source: hipMemcpyAsync stages it before returning
-    SMX_HIP(hipMemcpyAsync(b->d_inc + v, &inc, 4, hipMemcpyHostToDevice, b->stream));
-    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (b->stage_pos == smx_bank::STAGE_SLOTS) {            // ring full: let the copies drain
+        SMX_HIP(hipStreamSynchronize(b->stream));
+        b->stage_pos = 0;
+    }
+    uint32_t *slot = b->h_stage + b->stage_pos++;
+    *slot = inc;
+    SMX_HIP(hipMemcpyAsync(b->d_inc + v, slot, 4, hipMemcpyHostToDevice, b->stream));
     b->free_map.set_free(v, inc == 0);
     return SMX_OK;
 }
@@ -303,11 +317,22 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
 
 extern "C" void *smx_bank_bus_dev(smx_bank *b) { return b ? b->d_bus[b->bus_cur] : nullptr; }
 
+// process_midi dispatch (linux/synth.c:236-258) for one event, on the bank
+extern "C" int smx_bank_midi_event(smx_bank *b, const uint8_t *msg, size_t size)
+{
+    if (!b || (size && !msg)) return SMX_E_ARG;
+    if (size != 3) return SMX_OK;
+    if (msg[0] == 0x90) return msg[2] == 0 ? smx_bank_note_off(b, msg[1]) : smx_bank_note_on(b, msg[1]);
+    if (msg[0] == 0x80) return smx_bank_note_off(b, msg[1]);
+    return SMX_OK;                                          // CC 23..31 on 0xB0: accepted, no action
+}
+
 extern "C" int smx_bank_sync(smx_bank *b)
 {
     if (!b) return SMX_E_ARG;
     SMX_HIP(hipSetDevice(b->device));
     SMX_HIP(hipStreamSynchronize(b->stream));
+    b->stage_pos = 0;
     if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
     return SMX_OK;
 }

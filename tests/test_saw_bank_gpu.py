@@ -207,3 +207,25 @@ def test_carry_formulation_extreme_increments(smx, orc):
     # 2^22 voices x 600 frames: many chunks per launch (MULTI form), 2.5e9 voice-samples
     m = 1 << 22
     _check(smx, orc, np.ascontiguousarray(inc[:m]), np.ascontiguousarray(state[:m]), [600, 513])
+
+
+def test_midi_event_bursts_without_sync(smx, orc):
+    """Bursts of MIDI events queued behind each other on the bank's stream (more than the
+    4096-slot staging ring between two blocks) must land before the next block's kernel."""
+    n = 3000
+    bank = smx.SawBank(n)
+    n2v = np.zeros(128, np.int32)
+    inc = np.zeros(n, np.uint32)
+    st = np.zeros(n, np.uint32)
+    rng = np.random.default_rng(21)
+    for burst in (10, 5000, 300):
+        for _ in range(burst):
+            msg = np.array([[0x90, 0x80][int(rng.random() < 0.3)], int(rng.integers(0, 128)), int(rng.integers(0, 2)) * 90], np.uint8)
+            bank.midi_event(msg)
+            orc.orc_midi_event(n2v, inc, n, msg, 3)
+        bus, _ = bank.run(64)
+        obus, _ = oracle.synth_run(orc, inc, st, 64)
+        assert np.array_equal(bus, obus)
+    ginc, gst = bank.read()
+    assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+    bank.close()
