@@ -199,6 +199,10 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): libraries that print banners at init (RCCL
+    # prints its version block to stdout) are pointed at stderr for the whole run.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -305,7 +309,8 @@ def main():
             line["cpu_baseline_parallel"] = par
         if world == 1 and not a.no_also:
             line["also"] = also_workloads(sta, synthetic, tab, bank, a.voices)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist:
         dist.barrier()          # every rank is done with its communicator before any is torn down
     bank.close()

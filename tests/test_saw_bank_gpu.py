@@ -229,3 +229,13 @@ def test_midi_event_bursts_without_sync(smx, orc):
     ginc, gst = bank.read()
     assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
     bank.close()
+
+
+def test_long_blocks_grow_the_bus(smx, orc, inc_table):
+    """Blocks longer than the initial 4096-frame bus capacity: the bus buffers (and, for a
+    big bank, the carry formulation's scratch slots) are reallocated between blocks."""
+    inc, state = synthetic.saw_bank(1500, 0x5EED0B05, inc_table, active_fraction=0.8)
+    _check(smx, orc, inc, state, [64, 10000, 7, 4097])
+    n = 1 << 20
+    inc, state = synthetic.saw_bank(n, 0x5EED0B06, inc_table)
+    _check(smx, orc, inc, state, [64, 4500, 64])          # 4500 frames x 2^20 voices: carry path, 71 chunks
