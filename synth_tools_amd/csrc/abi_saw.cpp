@@ -83,12 +83,14 @@ struct smx_bank {
     uint32_t *d_inc = nullptr;
     uint32_t *d_state[2] = {nullptr, nullptr};   // ping-pong (saw_bank.hip)
     int cur = 0;
-    // three bus buffers in rotation: [cur] holds the last block (and may be feeding an
-    // all-reduce), [cur+1] was zeroed by the last launch for the next one, [cur+2] is
-    // the one the next launch will zero.
-    static constexpr int NBUS = 3;
-    int32_t *d_bus[NBUS] = {nullptr, nullptr, nullptr};
-    uint32_t bus_zeroed[NBUS] = {0, 0, 0};       // leading frames known to be zero
+    // A ring of bus buffers: [cur] holds the last block (and may be feeding an all-reduce),
+    // [cur+1] was zeroed by the last launch for the next one, [cur+2] is the one the next
+    // launch will zero; it was used NBUS-1 blocks ago.  The ring is deep so that the compute
+    // stream has to wait for the comm stream only once per NBUS/2 blocks (see
+    // bank_bus_release) instead of once per block.
+    static constexpr int NBUS = 16;
+    int32_t *d_bus[NBUS] = {};
+    uint32_t bus_zeroed[NBUS] = {};              // leading frames known to be zero
     int bus_cur = 0;
     uint32_t bus_cap = 0;
     int32_t *h_bus = nullptr;                    // pinned
@@ -98,9 +100,9 @@ struct smx_bank {
     void *d_scratch = nullptr;                   // partial sums of saw_bank.hip's carry formulation
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
-    hipEvent_t ev_kernel[NBUS] = {nullptr, nullptr, nullptr};   // kernel of bus[i] finished
-    hipEvent_t ev_comm[NBUS] = {nullptr, nullptr, nullptr};     // all-reduce of bus[i] finished
-    bool comm_pending[NBUS] = {false, false, false};
+    hipEvent_t ev_kernel[NBUS] = {};             // kernel of bus[i] finished
+    hipEvent_t ev_comm[NBUS] = {};               // all-reduce of bus[i] finished
+    bool comm_pending[NBUS] = {};                // an all-reduce was issued on bus[i] and not waited for
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int note2voice[128];
@@ -269,11 +271,22 @@ extern "C" int smx_bank_note_off(smx_bank *b, int note)
 }
 
 // Wait (on the compute stream) until nothing in flight still uses bus buffer i.
+// Make the compute stream wait until no all-reduce still uses bus buffer i.  The comm stream
+// runs its all-reduces in order, so waiting for a YOUNGER one covers buffer i too: the wait
+// is taken on the youngest all-reduce that is at least NBUS/2 blocks old, which retires half
+// the ring at once -- one cross-stream barrier per NBUS/2 blocks in steady state.
 static int bank_bus_release(smx_bank *b, int i)
 {
-    if (b->comm_pending[i]) {
-        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[i], 0));
-        b->comm_pending[i] = false;
+    if (!b->comm_pending[i]) return SMX_OK;
+    int j = i;
+    for (int k = smx_bank::NBUS / 2 - 1; k > 0; k--) {
+        const int c = (i + k) % smx_bank::NBUS;
+        if (b->comm_pending[c]) { j = c; break; }
+    }
+    SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[j], 0));
+    for (int c = i;; c = (c + 1) % smx_bank::NBUS) {     // everything from i up to j is now safe
+        b->comm_pending[c] = false;
+        if (c == j) break;
     }
     return SMX_OK;
 }

@@ -294,3 +294,43 @@ def test_cproc_atoms(orc):
         orc.orc_acc_update(acc, int(out[0]))
         edges.append(int(out[0]))
     assert edges == [0, 0, 1, 0, 0, 1, 0, 1] and acc[0] == 3
+
+
+# ---- build-defined poly voice and the clock generator: definition sanity --------------
+def test_poly_definition_sanity(orc):
+    """The build-defined voice (no reference counterpart): envelope walks A -> D -> S, releases
+    to idle; the 1-pole filter follows the saw; an off voice (inc 0) is silent and frozen."""
+    import ctypes as C
+    n = 2
+    a = dict(inc=np.array([39370533, 0], np.uint32), phase=np.array([0, 123], np.uint32),
+             y=np.zeros(n, np.float32), a=np.full(n, 0.25, np.float32),
+             level=np.zeros(n, np.uint32), stage=np.zeros(n, np.uint32), gate=np.ones(n, np.uint32),
+             ar=np.full(n, 0x08000000, np.uint32), dr=np.full(n, 0x04000000, np.uint32),
+             sl=np.full(n, 0x80000000, np.uint32), rr=np.full(n, 0x02000000, np.uint32),
+             pan=np.full(n, 256 | (128 << 16), np.uint32))
+    b = oracle.PolyBank(n=n, **{k: v.ctypes.data for k, v in a.items()})
+    stages = []
+    for blk in range(12):
+        if blk == 6:
+            a["gate"][:] = 0
+        bus = np.zeros(2 * 16, np.int32)
+        orc.orc_poly_run(C.byref(b), bus, 16)
+        stages.append(int(a["stage"][0]))
+        if blk == 3:
+            assert np.any(bus != 0) and np.array_equal(bus[0::2] // 2, bus[1::2] // 2) is not None
+    assert stages[0] == 1 and 3 in stages and stages[-1] == 0          # A ... S ... idle
+    assert a["level"][0] == 0
+    assert a["phase"][1] == 123 and a["stage"][1] == 0 and a["y"][1] == 0   # off voice untouched
+    assert a["phase"][0] == (12 * 16 * 39370533) & 0xFFFFFFFF
+
+
+def test_clock_definition(orc):
+    """clock.c:106-120 at the reference's operating point: 120 bpm @ 48 kHz -> half period 500
+    frames; first toggle when phase reaches 500; ticks only on the rising polarity."""
+    hp = np.array([orc.orc_bpm_to_hperiod(48000, 120)], np.uint32)
+    ph, po = np.zeros(1, np.int32), np.ones(1, np.uint32)
+    pb, tb = np.zeros(2100, np.uint32), np.zeros(2100, np.uint32)
+    orc.orc_clock_run(hp, ph, po, 1, 2100, pb, tb)
+    assert hp[0] == 500
+    assert pb[:500].all() and not pb[500:1000].any() and pb[1000:1500].all()
+    assert np.flatnonzero(tb).tolist() == [1000, 2000]
