@@ -139,6 +139,13 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
     out.append({"workload": "c2: saw bank, 65536 voices, 64 frames/step (launch-bound)",
                 "value": round(65536 * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s",
                 "ms_per_step": round(ms, 5)})
+    b = sta.SawBank(65536)
+    b.load(inc, st)
+    ms = time_saw(sta, b, 4096, 50, 5)
+    b.close()
+    out.append({"workload": "c2: saw bank, 65536 voices, 4096 frames/launch (64 JACK blocks per launch, time-parallel chunks)",
+                "value": round(65536 * 4096 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s",
+                "ms_per_step": round(ms, 5)})
     # BASELINE config 3: 1 Mi PDM channels (mod_pdm.c integer path), dither 0 and seeded
     n, nt = 1 << 20, 4096
     sp, ac = synthetic.pdm_bank(n, 0x5EED0003)

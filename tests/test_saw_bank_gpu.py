@@ -239,3 +239,34 @@ def test_long_blocks_grow_the_bus(smx, orc, inc_table):
     n = 1 << 20
     inc, state = synthetic.saw_bank(n, 0x5EED0B06, inc_table)
     _check(smx, orc, inc, state, [64, 4500, 64])          # 4500 frames x 2^20 voices: carry path, 71 chunks
+
+
+def test_randomised_block_sequences(smx, orc, inc_table):
+    """Seeded fuzz: random bank sizes around every kernel-selection threshold, random block
+    lengths, random activity, with MIDI events and bulk reloads between blocks."""
+    rng = np.random.default_rng(0xF022)
+    sizes = [1, 63, 64, 65, 255, 1023, 1024, 1025, 4096, 65535, 65537, (1 << 20) - 1, (1 << 20), (1 << 20) + 1]
+    for trial in range(14):
+        n = sizes[trial]
+        inc, state = synthetic.saw_bank(n, 0xF000 + trial, inc_table, active_fraction=float(rng.choice([0.0, 0.3, 1.0])))
+        if trial % 3 == 0:                                     # arbitrary (non-table) increments and phases
+            inc = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        bank = smx.SawBank(n)
+        bank.load(inc, state)
+        n2v = np.zeros(128, np.int32)
+        st = state.copy()
+        inc = inc.copy()
+        for _ in range(6):
+            nf = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 257]))
+            if n <= 4096 and rng.random() < 0.5:
+                for _ in range(int(rng.integers(1, 20))):
+                    msg = np.array([0x90, int(rng.integers(0, 128)), int(rng.integers(0, 2)) * 64], np.uint8)
+                    bank.midi_event(msg)
+                    orc.orc_midi_event(n2v, inc, n, msg, 3)
+            bus, vec = bank.run(nf)
+            obus, ovec = oracle.synth_run(orc, inc, st, nf)
+            assert np.array_equal(bus, obus), "n=%d nf=%d" % (n, nf)
+            assert np.array_equal(vec.view(np.uint32), ovec.view(np.uint32))
+        ginc, gst = bank.read()
+        assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+        bank.close()
