@@ -16,6 +16,7 @@
  *
  *   synth.dynamic.host.elf                       real JACK, 64-voice drop-in path
  *   SYNTH_VOICES=1048576 synth.dynamic.host.elf  real JACK, N-voice bank path
+ *   SYNTH_PIPELINE=1 ...                         bank path returns block k-1 while k computes
  *   synth.dynamic.host.elf --fake-jack NBLOCKS NFRAMES EVENTS.bin OUT.f32
  *       EVENTS.bin: records {u32 block; u8 size; u8 bytes[3]} delivered to
  *       midi_in at the start of that block; OUT.f32: NBLOCKS*NFRAMES floats.
@@ -149,6 +150,7 @@ int main(int argc, char **argv) {
         midi_in = FAKE_MIDI_PORT;
         audio_out = FAKE_AUDIO_PORT;
         if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
+        if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
         synth_init(&synth);
         FILE *out = fopen(argv[5], "wb");
         ASSERT(out);
@@ -176,6 +178,7 @@ int main(int argc, char **argv) {
         ASSERT(midi_in = jack.port_register(client, "midi_in", JACK_DEFAULT_MIDI_TYPE, JackPortIsInput, 0));
         ASSERT(audio_out = jack.port_register(client, "audio_out", JACK_DEFAULT_AUDIO_TYPE, JackPortIsOutput, 0));
         if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
+        if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
         synth_init(&synth);
         jack.set_process_callback(client, process, 0);
         ASSERT(!mlockall(MCL_CURRENT | MCL_FUTURE));

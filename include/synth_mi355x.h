@@ -95,6 +95,14 @@ int smx_bank_midi_event(smx_bank *b, const uint8_t *msg, size_t size);
  * linux/synth.c:170-179).  Synchronous. */
 int smx_bank_run(smx_bank *b, float *vec, int32_t *bus, int n);
 
+/* Block mode of smx_bank_run.  SMX_BLOCK_SYNC (default) is the reference's behaviour:
+ * the call returns this block's samples.  SMX_BLOCK_PIPELINED launches block k and
+ * returns block k-1 (silence on the first call), so a real-time thread never waits for
+ * a kernel it has just launched: one block of added latency. */
+#define SMX_BLOCK_SYNC      0
+#define SMX_BLOCK_PIPELINED 1
+int smx_bank_set_block_mode(smx_bank *b, int mode);
+
 /* Asynchronous form: enqueue one block of n frames on the bank's stream and
  * leave the int32 bus in device memory (smx_bank_bus_dev).  No host sync. */
 int   smx_bank_run_async(smx_bank *b, int n);

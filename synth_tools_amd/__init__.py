@@ -85,6 +85,7 @@ ABI = [
     ("smx_bank_note_off", C.c_int, [_P, C.c_int]),
     ("smx_bank_midi_event", C.c_int, [_P, _u8, C.c_size_t]),
     ("smx_bank_run", C.c_int, [_P, _P, _P, C.c_int]),
+    ("smx_bank_set_block_mode", C.c_int, [_P, C.c_int]),
     ("smx_bank_run_async", C.c_int, [_P, C.c_int]),
     ("smx_bank_bus_dev", _P, [_P]),
     ("smx_bank_sync", C.c_int, [_P]),
@@ -230,6 +231,9 @@ class SawBank:
 
     def note_off(self, note):
         _check(lib().smx_bank_note_off(self._h, note), "smx_bank_note_off")
+
+    def set_block_mode(self, pipelined):
+        _check(lib().smx_bank_set_block_mode(self._h, 1 if pipelined else 0), "smx_bank_set_block_mode")
 
     def midi_event(self, msg):
         m = np.ascontiguousarray(msg, np.uint8)

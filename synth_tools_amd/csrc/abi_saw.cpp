@@ -94,6 +94,14 @@ struct smx_bank {
     int bus_cur = 0;
     uint32_t bus_cap = 0;
     int32_t *h_bus = nullptr;                    // pinned
+    // pipelined block mode (smx_bank_set_block_mode): the bus of block k is copied to pinned
+    // memory behind its kernel and handed out by the call that launches block k+1
+    int block_mode = 0;
+    int32_t *h_pipe[2] = {nullptr, nullptr};
+    uint32_t pipe_cap = 0;
+    hipEvent_t ev_pipe[2] = {nullptr, nullptr};
+    int pipe_n[2] = {0, 0};                      // frames held by each slot (0: nothing yet)
+    uint32_t pipe_k = 0;
     uint32_t *h_stage = nullptr;                 // pinned ring of pending inc[] updates (note on/off)
     uint32_t stage_pos = 0;
     static constexpr uint32_t STAGE_SLOTS = 4096;
@@ -197,6 +205,10 @@ extern "C" void smx_bank_destroy(smx_bank *b)
     }
     if (b->h_bus) (void)hipHostFree(b->h_bus);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
+    for (int i = 0; i < 2; i++) {
+        if (b->h_pipe[i]) (void)hipHostFree(b->h_pipe[i]);
+        if (b->ev_pipe[i]) (void)hipEventDestroy(b->ev_pipe[i]);
+    }
     if (b->d_scratch) (void)hipFree(b->d_scratch);
     if (b->ev_t0) (void)hipEventDestroy(b->ev_t0);
     if (b->ev_t1) (void)hipEventDestroy(b->ev_t1);
@@ -366,8 +378,66 @@ extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
     return SMX_OK;
 }
 
+extern "C" int smx_bank_set_block_mode(smx_bank *b, int mode)
+{
+    if (!b || (mode != SMX_BLOCK_SYNC && mode != SMX_BLOCK_PIPELINED)) { set_error("smx_bank_set_block_mode: mode %d", mode); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    if (mode == SMX_BLOCK_PIPELINED && !b->ev_pipe[0]) {
+        SMX_HIP(hipEventCreateWithFlags(&b->ev_pipe[0], hipEventDisableTiming));
+        SMX_HIP(hipEventCreateWithFlags(&b->ev_pipe[1], hipEventDisableTiming));
+    }
+    b->block_mode = mode;
+    b->pipe_n[0] = b->pipe_n[1] = 0;
+    b->pipe_k = 0;
+    return SMX_OK;
+}
+
+// Pipelined: launch block k, copy its bus to pinned slot k&1 behind the kernel, and return
+// block k-1 from the other slot, which finished while the caller was away: the JACK thread
+// never waits for a kernel it has just launched (one block of added latency).
+static int bank_run_pipelined(smx_bank *b, float *vec, int32_t *bus, int n)
+{
+    if ((uint32_t)n > b->pipe_cap) {
+        SMX_HIP(hipStreamSynchronize(b->stream));
+        const uint32_t cap = smx::round_up((uint32_t)n < 4096u ? 4096u : (uint32_t)n, 4096);
+        for (int i = 0; i < 2; i++) {
+            if (b->h_pipe[i]) SMX_HIP(hipHostFree(b->h_pipe[i]));
+            b->h_pipe[i] = nullptr;
+            SMX_HIP(hipHostMalloc((void **)&b->h_pipe[i], (size_t)cap * 4, hipHostMallocDefault));
+            b->pipe_n[i] = 0;
+        }
+        b->pipe_cap = cap;
+    }
+    int rv = smx_bank_run_async(b, n);
+    if (rv) return rv;
+    const int cur = b->pipe_k & 1, prev = cur ^ 1;
+    const int bi = b->bus_cur;
+    if (b->comm_pending[bi]) {
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
+        b->comm_pending[bi] = false;
+    }
+    SMX_HIP(hipMemcpyAsync(b->h_pipe[cur], b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    SMX_HIP(hipEventRecord(b->ev_pipe[cur], b->stream));
+    b->pipe_n[cur] = n;
+    b->pipe_k++;
+    const int have = b->pipe_n[prev];
+    if (have) SMX_HIP(hipEventSynchronize(b->ev_pipe[prev]));      // normally long complete
+    for (int i = 0; i < n; i++) {
+        const int32_t v = i < have ? b->h_pipe[prev][i] : 0;       // the first call returns silence
+        if (bus) bus[i] = v;
+        if (vec) vec[i] = bus_to_float(v);
+    }
+    return SMX_OK;
+}
+
 extern "C" int smx_bank_run(smx_bank *b, float *vec, int32_t *bus, int n)
 {
+    if (!b || n <= 0) { set_error("smx_bank_run: bad args"); return SMX_E_ARG; }
+    if (b->block_mode == SMX_BLOCK_PIPELINED) {
+        SMX_HIP(hipSetDevice(b->device));
+        return bank_run_pipelined(b, vec, bus, n);
+    }
     int rv = smx_bank_run_async(b, n);
     if (rv) return rv;
     return smx_bank_fetch(b, vec, bus, n);

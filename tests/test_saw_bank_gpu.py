@@ -270,3 +270,30 @@ def test_randomised_block_sequences(smx, orc, inc_table):
         ginc, gst = bank.read()
         assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
         bank.close()
+
+
+def test_pipelined_block_mode(smx, orc, inc_table):
+    """SMX_BLOCK_PIPELINED: smx_bank_run returns the previous block (silence first), state and
+    note events behave as in sync mode; switching back to sync returns current blocks."""
+    n = 5000
+    inc, state = synthetic.saw_bank(n, 0x5EED0F1F, inc_table)
+    bank = smx.SawBank(n)
+    bank.load(inc, state)
+    bank.set_block_mode(True)
+    st = state.copy()
+    want = [np.zeros(64, np.int32)]
+    for k in range(6):
+        nf = 64 if k != 3 else 32
+        bus, vec = bank.run(nf)
+        prev = want[-1]
+        exp = np.zeros(nf, np.int32)
+        m = min(nf, len(prev))
+        exp[:m] = prev[:m]
+        assert np.array_equal(bus, exp), "block %d" % k
+        assert np.array_equal(vec.view(np.uint32), np.array([orc.orc_bus_to_float(int(v)) for v in exp], np.float32).view(np.uint32))
+        want.append(oracle.synth_run(orc, inc, st, nf)[0])
+    assert np.array_equal(bank.read()[1], st)                # phases are those of the launched blocks
+    bank.set_block_mode(False)
+    bus, _ = bank.run(64)
+    assert np.array_equal(bus, oracle.synth_run(orc, inc, st, 64)[0])
+    bank.close()
