@@ -126,8 +126,8 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
                     "value": round(vs / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
                     "hbm_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                     # vector ops per voice-sample: 2.5 (direct) / 1.5 + 1 scalar (carry formulation)
-                    "formulation": "carry" if frames > 32 and voices * frames >= 1 << 31 else "direct",
-                    "int_valu_frac": round(vs * (1.5 if frames > 32 and voices * frames >= 1 << 31 else 2.5)
+                    "formulation": "carry" if frames > 16 and voices * frames >= 1 << 31 else "direct",
+                    "int_valu_frac": round(vs * (1.5 if frames > 16 and voices * frames >= 1 << 31 else 2.5)
                                            / 1e12 / INT_VALU_PEAK_TOPS, 4),
                     "max_voices_48k": int(vs / 48000)})
     # BASELINE config 2: 65 536 voices, 64-frame blocks

@@ -20,7 +20,7 @@
 // banks still fill the chip.  State is ping-ponged (state_in -> state_out) so
 // that chunks never read what another chunk has already advanced.
 //
-// Long blocks of big banks (> 32 frames, >= 2^20 voices) take a second formulation
+// Long blocks of big banks (> 16 frames, >= 2^31 voice-samples) take a second formulation
 // (saw_bank_carry_kernel) that needs 2 instead of 2.5 vector ops per voice-sample:
 // with u = state ^ 0x80000000 (offset binary) the arithmetic shift becomes a logical
 // one, (int)state >> 4 == (u >> 4) - 2^27, and because every term is a floor,
@@ -80,11 +80,29 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
 #pragma unroll
     for (int t = 0; t < TC; t++) acc[t] = 0;
 
-    for (uint32_t g = blockIdx.x * 256u + tid; g < ngroups; g += gridDim.x * 256u) {
+    // VW == 4: ngroups is a multiple of 256 (n_pad of 1024), so the grid-stride loop runs over
+    // whole workgroup rows with a wave-uniform trip count, and the next row's 32 bytes per lane
+    // are requested before the arithmetic on the current row (software prefetch).
+    const uint32_t nrows = ngroups >> 8;
+    u32x4 a_next = 0, b_next = 0;
+    if constexpr (VW == 4) {
+        if (blockIdx.x < nrows) {
+            a_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + blockIdx.x * 256u + tid);
+            b_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + blockIdx.x * 256u + tid);
+        }
+    }
+    const uint32_t g_first = (VW == 4) ? blockIdx.x : blockIdx.x * 256u + tid;
+    const uint32_t g_end = (VW == 4) ? nrows : ngroups;
+    const uint32_t g_step = (VW == 4) ? gridDim.x : gridDim.x * 256u;
+    for (uint32_t gi = g_first; gi < g_end; gi += g_step) {
+        const uint32_t g = (VW == 4) ? gi * 256u + tid : gi;
         uint32_t vi[VW], vs[VW];
         if constexpr (VW == 4) {
-            const u32x4 a = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + g);
-            const u32x4 b = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + g);
+            const u32x4 a = a_next, b = b_next;
+            const uint32_t rn = min(gi + gridDim.x, nrows - 1) * 256u + tid;   // last trip re-reads its row
+            a_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + rn);
+            b_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + rn);
+            asm volatile("" ::: "memory");      // keep the store below the youngest memory operation
             vi[0] = a.x; vi[1] = a.y; vi[2] = a.z; vi[3] = a.w;
             vs[0] = b.x; vs[1] = b.y; vs[2] = b.z; vs[3] = b.w;
         } else {
@@ -180,7 +198,8 @@ __device__ __forceinline__ uint32_t carry_step4(uint32_t &u0, uint32_t &u1, uint
 // advanced phases.  The single-chunk form keeps its memory operations in straight-line
 // order (load, load, store) so that the wait for the prefetched loads is vmcnt(1) and the
 // store's completion is never waited for inside the loop.
-template <bool NT, bool MULTI>
+// TC: frames computed per chunk (64, or 32 for single-chunk blocks of 17..32 frames).
+template <bool NT, bool MULTI, int TC>
 __global__ __launch_bounds__(256)
 void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
                            uint32_t *__restrict__ st_out, SawPartial *__restrict__ partial,
@@ -196,10 +215,10 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     if (tid < 2) S[tid] = 0;
     __syncthreads();
 
-    uint32_t cnt[64];                              // per-lane carry counts (voices 0/1)
+    uint32_t cnt[TC];                              // per-lane carry counts (voices 0/1)
     uint32_t W[32];                                // wave-uniform counts (voices 2/3): frames t | t+32 << 16
 #pragma unroll
-    for (int t = 0; t < 64; t++) cnt[t] = 0;
+    for (int t = 0; t < TC; t++) cnt[t] = 0;
 #pragma unroll
     for (int t = 0; t < 32; t++) W[t] = 0;
     unsigned long long sumU = 0, sumI = 0;
@@ -239,7 +258,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         atomicAdd(&H[((u2 & 15) << 4) | (a.z & 15)], 1u);
         atomicAdd(&H[((u3 & 15) << 4) | (a.w & 15)], 1u);
 #pragma unroll
-        for (int t = 0; t < 64; t++) {
+        for (int t = 0; t < TC; t++) {
             const uint32_t c = carry_step4(u0, u1, u2, u3, a.x, a.y, a.z, a.w, cnt[t]);
             W[t & 31] += (t < 32) ? c : (c << 16);
         }
@@ -247,7 +266,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
 
     // per-lane counts -> M[t][lane]; per-wave scalar counts -> M[t][64]
 #pragma unroll
-    for (int t = 0; t < 64; t++) atomicAdd(&M[t][lane], cnt[t]);
+    for (int t = 0; t < TC; t++) atomicAdd(&M[t][lane], cnt[t]);
     if (lane == 0) {
 #pragma unroll
         for (int t = 0; t < 32; t++) {
@@ -429,7 +448,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
     // measured crossover on MI355X: the carry formulation's fixed cost (histogram fold, slot
     // atomics, second kernel) pays off from about 2^31 voice-samples per launch
     const bool big = (unsigned long long)n_pad * nframes >= (1ull << 31);
-    if (nframes > 32 && n_pad >= (1u << 20) && big && d_scratch && !no_carry) {
+    if (nframes > 16 && n_pad >= (1u << 20) && big && d_scratch && !no_carry) {
         // carry-count formulation: 2 vector ops per voice-sample
         const uint32_t ngroups = n_pad / 4;
         const uint32_t gy = (nframes + 63) / 64;
@@ -442,12 +461,13 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
         const uint32_t trips = (ngroups + gx * 256u - 1) / (gx * 256u);
         if (trips <= 400 && (size_t)SAW_SLOTS * gy * sizeof(SawPartial) <= saw_scratch_bytes(nframes)) {
             auto *part = static_cast<SawPartial *>(d_scratch);     // all zero between launches
-#define SMX_CARRY_LAUNCH(NT_, MULTI_)                                                             \
-    hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_>), dim3(gx, gy), dim3(256), 0, stream, \
+#define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_)                                                             \
+    hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_>), dim3(gx, gy), dim3(256), 0, stream, \
                        d_inc, d_state_in, d_state_out, part, ngroups, nframes)
             const bool nt = n_pad >= (1u << 24);
-            if (gy == 1) { if (nt) SMX_CARRY_LAUNCH(true, false); else SMX_CARRY_LAUNCH(false, false); }
-            else         { if (nt) SMX_CARRY_LAUNCH(true, true);  else SMX_CARRY_LAUNCH(false, true); }
+            if (gy > 1)             { if (nt) SMX_CARRY_LAUNCH(true, true, 64);  else SMX_CARRY_LAUNCH(false, true, 64); }
+            else if (nframes > 32)  { if (nt) SMX_CARRY_LAUNCH(true, false, 64); else SMX_CARRY_LAUNCH(false, false, 64); }
+            else                    { if (nt) SMX_CARRY_LAUNCH(true, false, 32); else SMX_CARRY_LAUNCH(false, false, 32); }
 #undef SMX_CARRY_LAUNCH
             hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
                                d_bus_next, nframes, n_pad);

@@ -192,7 +192,7 @@ def test_carry_formulation_blocks(smx, orc, inc_table, frac):
     the direct formulation on the same bank."""
     n = (1 << 25) + 1000          # n * frames >= 2^31 selects the carry formulation for >= 64 frames
     inc, state = synthetic.saw_bank(n, 0x5EED0C00, inc_table, active_fraction=frac)
-    _check(smx, orc, inc, state, [64, 1, 65, 16, 100])
+    _check(smx, orc, inc, state, [64, 1, 65, 16, 100, 32, 17])
 
 
 def test_carry_formulation_extreme_increments(smx, orc):
