@@ -59,6 +59,10 @@ void synth_note_on (struct synth *x, int note);      /* linux/synth.c:156-160 */
 void synth_note_off(struct synth *x, int note);      /* linux/synth.c:161-165 */
 void synth_init    (struct synth *x);                /* linux/synth.c:204-206 */
 void synth_run     (struct synth *x, float *vec, int n); /* linux/synth.c:196-202 */
+/* The per-sample tick functions, linux/synth.c:169-181 and :182-195 (global symbols in
+ * the reference; synth_run calls the first n times). */
+float sum_tick_saw(struct synth *x);
+float sum_tick_square(struct synth *x);
 /* linux/synth.c:118-125 and :145-154, also global symbols in the reference. */
 phasor_t note_to_inc(int note);
 int      voice_alloc(struct synth *x);

@@ -73,6 +73,8 @@ ABI = [
     ("synth_note_off", None, [C.POINTER(Synth), C.c_int]),
     ("synth_init", None, [C.POINTER(Synth)]),
     ("synth_run", None, [C.POINTER(Synth), _f32, C.c_int]),
+    ("sum_tick_saw", C.c_float, [C.POINTER(Synth)]),
+    ("sum_tick_square", C.c_float, [C.POINTER(Synth)]),
     ("note_to_inc", C.c_uint32, [C.c_int]),
     ("voice_alloc", C.c_int, [C.POINTER(Synth)]),
     ("synth_midi_event", None, [C.POINTER(Synth), _u8, C.c_size_t]),

@@ -108,9 +108,9 @@ extern "C" void synth_midi_event(struct synth *x, const uint8_t *msg, size_t siz
     }                                         // CC 23..31 on 0xB0: accepted, no action (:240-245)
 }
 
-extern "C" void synth_run(struct synth *x, float *vec, int n)
+// Run the caller's 64 voices through the scratch bank: upload, n frames, download.
+static void dropin_run(struct synth *x, float *vec, int n, bool square)
 {
-    if (n <= 0) return;
     std::lock_guard<std::mutex> lock(g_dropin_mu);
     if (!g_dropin) {
         g_dropin = smx_bank_create(64, 0);
@@ -119,8 +119,29 @@ extern "C" void synth_run(struct synth *x, float *vec, int n)
     uint32_t inc[64], state[64];
     for (int v = 0; v < 64; v++) { inc[v] = x->voice[v].note_inc; state[v] = x->voice[v].note_state; }
     SMX_ASSERT_OK(smx_bank_load(g_dropin, inc, state), "synth_run: load");
-    SMX_ASSERT_OK(smx_bank_run(g_dropin, vec, nullptr, n), "synth_run: run");
+    if (square) SMX_ASSERT_OK(smx_bank_run_square(g_dropin, vec, n), "sum_tick_square: run");
+    else        SMX_ASSERT_OK(smx_bank_run(g_dropin, vec, nullptr, n), "synth_run: run");
     SMX_ASSERT_OK(smx_bank_read(g_dropin, nullptr, state), "synth_run: read");
     for (int v = 0; v < 64; v++) x->voice[v].note_state = state[v];
 }
 
+extern "C" void synth_run(struct synth *x, float *vec, int n)
+{
+    if (n <= 0) return;
+    dropin_run(x, vec, n, false);
+}
+
+// linux/synth.c:169-181 and :182-195 are global symbols in the reference too: one sample.
+extern "C" float sum_tick_saw(struct synth *x)
+{
+    float v = 0.0f;
+    dropin_run(x, &v, 1, false);
+    return v;
+}
+
+extern "C" float sum_tick_square(struct synth *x)
+{
+    float v = 0.0f;
+    dropin_run(x, &v, 1, true);
+    return v;
+}

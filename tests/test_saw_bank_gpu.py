@@ -297,3 +297,23 @@ def test_pipelined_block_mode(smx, orc, inc_table):
     bus, _ = bank.run(64)
     assert np.array_equal(bus, oracle.synth_run(orc, inc, st, 64)[0])
     bank.close()
+
+
+def test_dropin_tick_functions(smx, orc):
+    """sum_tick_saw / sum_tick_square on the caller's struct synth (linux/synth.c:169-195)."""
+    L = smx.lib()
+    x = smx.Synth()
+    L.synth_init(C.byref(x))
+    inc = np.zeros(64, np.uint32)
+    st = np.zeros(64, np.uint32)
+    n2v = np.zeros(128, np.int32)
+    for note in (40, 52, 59, 64, 100):
+        L.synth_note_on(C.byref(x), note)
+        orc.orc_note_on(n2v, inc, 64, note)
+    for i in range(40):
+        if i % 2:
+            got, want = L.sum_tick_square(C.byref(x)), orc.orc_sum_tick_square(inc, st, 64)
+        else:
+            got, want = L.sum_tick_saw(C.byref(x)), orc.orc_bus_to_float(orc.orc_sum_tick_saw(inc, st, 64))
+        assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32)
+    assert [x.voice[v].note_state for v in range(64)] == st.tolist()
