@@ -44,24 +44,39 @@ void poly_bank_kernel(smx::PolyArrays p, int32_t *__restrict__ bus_lr, uint32_t 
         if (p.gate[v]) { if (stage == ENV_IDLE || stage == ENV_R) stage = ENV_A; }
         else           { if (stage != ENV_IDLE) stage = ENV_R; }
 
+        // ADSR as "move the level towards a target at a rate; on arrival enter the next stage".
+        // The per-frame work is the same few operations in every stage; the stage-specific
+        // parameters live in registers and are rewritten only when some lane of the wave
+        // arrives (rare: a stage lasts 10^2..10^5 frames), behind a wave-uniform branch.
+        //   A: up,   rate ar, arrival = 32-bit wrap  -> level MAX,  next D
+        //   D: down, rate dr, target sl              -> level sl,   next S
+        //   R: down, rate rr, target 0               -> level 0,    next idle
+        //   S, idle: hold (up at rate 0 never arrives); level is sl / 0 on entry
+        bool up;
+        uint32_t rate, target, reach_val, next;
+        auto enter = [&](uint32_t st) {
+            stage = st;
+            up = (st == ENV_A) || (st == ENV_S) || (st == ENV_IDLE);
+            rate = st == ENV_A ? ar : st == ENV_D ? dr : st == ENV_R ? rr : 0u;
+            target = st == ENV_D ? sl : 0u;
+            reach_val = st == ENV_A ? 0xFFFFFFFFu : st == ENV_D ? sl : 0u;
+            next = st == ENV_A ? (uint32_t)ENV_D : st == ENV_D ? (uint32_t)ENV_S : (uint32_t)ENV_IDLE;
+        };
+        enter(stage);
+        if (stage == ENV_S) level = sl;                      // "S: level = sl" / "idle: level = 0"
+        if (stage == ENV_IDLE) level = 0;
+
         for (uint32_t i = 0; i < nframes; i++) {
             const float x = __fmul_rn((float)(int32_t)phase, 0x1p-31f);
             phase += inc;
             const float t = __fsub_rn(x, y);
             y = __fadd_rn(y, __fmul_rn(a, t));
-            // ADSR stage machine, branch-free (lanes of a wave sit in different stages):
-            // every candidate is computed, the lane's stage selects one.
-            const uint32_t up = level + ar;                      // attack
-            const bool a_top = up < level;                       //   wrapped: reached the top
-            const bool d_done = (level <= sl) || (level - sl <= dr);   // decay reached sustain
-            const bool r_done = level <= rr;                     // release reached zero
-            uint32_t nl = 0, ns = ENV_IDLE;
-            if (stage == ENV_A) { nl = a_top ? 0xFFFFFFFFu : up;    ns = a_top ? ENV_D : ENV_A; }
-            if (stage == ENV_D) { nl = d_done ? sl : level - dr;    ns = d_done ? ENV_S : ENV_D; }
-            if (stage == ENV_S) { nl = sl;                          ns = ENV_S; }
-            if (stage == ENV_R) { nl = r_done ? 0u : level - rr;    ns = r_done ? ENV_IDLE : ENV_R; }
-            level = nl;
-            stage = ns;
+            const uint32_t nl_u = level + rate, nl_d = level - rate;
+            const bool arrived = up ? (nl_u < level) : (level <= target || level - target <= rate);
+            level = arrived ? reach_val : (up ? nl_u : nl_d);
+            if (__any(arrived)) {
+                if (arrived) enter(next);
+            }
             const float g = __fmul_rn((float)(level >> 8), 0x1p-24f);
             const float o = __fmul_rn(y, g);
             const int32_t q = (int32_t)__fmul_rn(o, 524288.0f);
