@@ -82,3 +82,29 @@ def test_c3_full_size_1m_channels(smx, orc):
     want = oracle.pdm_run(orc, np.ascontiguousarray(sp[sl]), oa, nt)
     assert np.array_equal(bits[:, lo // 32:(lo + 2048) // 32], want)
     bank.close()
+
+
+def test_c3_full_size_with_dither(smx, orc):
+    """1 Mi channels x 2048 ticks with a seeded dither stream (mod_pdm.c:261 mask): closed-form
+    accumulators and exact pulse counts, accu' = sum_t ((sp + d_t) mod 2^32) mod 2^32 and
+    pulses = floor(that sum / 2^32), plus a slice against the oracle."""
+    n, nt = 1 << 20, 2048
+    sp, accu = synthetic.pdm_bank(n, 0x5EED0033)
+    d = synthetic.dither_stream(nt, 0xD17D17, 0x0FFFFFFF)
+    bank = smx.PdmBank(n)
+    bank.load(sp, accu)
+    bits = bank.tick_n(nt, d)
+    _, gac = bank.read()
+    cols = np.r_[0:32, n // 3:n // 3 + 32, n - 32:n]
+    x = (sp[cols].astype(np.uint64)[None, :] + d.astype(np.uint64)[:, None]) & np.uint64(0xFFFFFFFF)
+    total = x.sum(axis=0)
+    assert np.array_equal(gac[cols], (total & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+    for k, c in enumerate(cols):
+        ones = int(((bits[:, c >> 5] >> np.uint32(c & 31)) & 1).sum())
+        assert ones == int(total[k] >> np.uint64(32))
+    lo = 9 * 1024
+    oa = np.zeros(1024, np.uint32)
+    want = oracle.pdm_run(orc, np.ascontiguousarray(sp[lo:lo + 1024]), oa, nt, d)
+    assert np.array_equal(bits[:, lo // 32:(lo + 1024) // 32], want)
+    assert np.array_equal(gac[lo:lo + 1024], oa)
+    bank.close()
