@@ -13,8 +13,8 @@ its shard to an int32 bus and the buses are summed with one RCCL all-reduce
 per step on a second stream (integer sum => bit-exact in any order).
 
 Metric: Gsamples/s = voice-samples advanced per second, whole job.
-Roofline: algorithmic HBM bytes per step (8 B read + 4 B written per voice,
-+ 4 B per bus frame) / average kernel time measured with HIP
+Roofline: algorithmic HBM bytes per step (8 B read per voice: inc and the lazily
+materialised phase base; nothing written back; + 4 B per bus frame) / average kernel time measured with HIP
 events on the bank's own stream, against 8 TB/s.
 cpu_baseline: the CPU oracle (a port of the reference loop), timed on this
 box's host cores on a bounded sample of the same bank (baseline only).
@@ -49,7 +49,8 @@ def parse():
 
 
 def saw_roofline(voices, frames, kernel_ms):
-    alg_bytes = 12.0 * voices + 4.0 * frames
+    # 8 B read per voice (inc + state0; the advanced phase is never written back: DESIGN.md §2)
+    alg_bytes = 8.0 * voices + 4.0 * frames
     gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
     return alg_bytes, gbs
 

@@ -81,8 +81,10 @@ struct smx_bank {
     uint32_t n = 0, n_pad = 0;
     int device = 0;
     uint32_t *d_inc = nullptr;
-    uint32_t *d_state[2] = {nullptr, nullptr};   // ping-pong (saw_bank.hip)
-    int cur = 0;
+    // Lazily materialised phases (saw_bank.hip): phase[v] = d_state0[v] + elapsed * d_inc[v].
+    // Blocks only read; the host adds the block length to `elapsed`.
+    uint32_t *d_state0 = nullptr;
+    uint32_t elapsed = 0;
     // A ring of bus buffers: [cur] holds the last block (and may be feeding an all-reduce),
     // [cur+1] was zeroed by the last launch for the next one, [cur+2] is the one the next
     // launch will zero; it was used NBUS-1 blocks ago.  The ring is deep so that the compute
@@ -102,9 +104,6 @@ struct smx_bank {
     hipEvent_t ev_pipe[2] = {nullptr, nullptr};
     int pipe_n[2] = {0, 0};                      // frames held by each slot (0: nothing yet)
     uint32_t pipe_k = 0;
-    uint32_t *h_stage = nullptr;                 // pinned ring of pending inc[] updates (note on/off)
-    uint32_t stage_pos = 0;
-    static constexpr uint32_t STAGE_SLOTS = 4096;
     void *d_scratch = nullptr;                   // partial sums of saw_bank.hip's carry formulation
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
@@ -166,8 +165,7 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     const size_t bytes = (size_t)b->n_pad * 4;
     if ((e = hipMalloc((void **)&b->d_inc, bytes)) != hipSuccess) return fail("hipMalloc inc", e);
-    for (int i = 0; i < 2; i++)
-        if ((e = hipMalloc((void **)&b->d_state[i], bytes)) != hipSuccess) return fail("hipMalloc state", e);
+    if ((e = hipMalloc((void **)&b->d_state0, bytes)) != hipSuccess) return fail("hipMalloc state", e);
     if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
     if ((e = hipEventCreate(&b->ev_t0)) != hipSuccess) return fail("event", e);
     if ((e = hipEventCreate(&b->ev_t1)) != hipSuccess) return fail("event", e);
@@ -177,13 +175,10 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     }
     // synth_init: bzero (linux/synth.c:204-206); padding voices stay off forever
     if ((e = hipMemsetAsync(b->d_inc, 0, bytes, b->stream)) != hipSuccess) return fail("memset", e);
-    for (int i = 0; i < 2; i++)
-        if ((e = hipMemsetAsync(b->d_state[i], 0, bytes, b->stream)) != hipSuccess) return fail("memset", e);
+    if ((e = hipMemsetAsync(b->d_state0, 0, bytes, b->stream)) != hipSuccess) return fail("memset", e);
     if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return fail("sync", e);
     memset(b->note2voice, 0, sizeof(b->note2voice));
     b->free_map.reset(b->n, true);
-    if ((e = hipHostMalloc((void **)&b->h_stage, smx_bank::STAGE_SLOTS * 4, hipHostMallocDefault)) != hipSuccess)
-        return fail("hipHostMalloc", e);
     if (bank_ensure_bus(b, 4096) != SMX_OK) { smx_bank_destroy(b); return nullptr; }
     return b;
 }
@@ -196,15 +191,13 @@ extern "C" void smx_bank_destroy(smx_bank *b)
     if (b->comm_stream) (void)hipStreamSynchronize(b->comm_stream);
     if (b->comm) (void)ncclCommDestroy(b->comm);
     if (b->d_inc) (void)hipFree(b->d_inc);
-    for (int i = 0; i < 2; i++)
-        if (b->d_state[i]) (void)hipFree(b->d_state[i]);
+    if (b->d_state0) (void)hipFree(b->d_state0);
     for (int i = 0; i < smx_bank::NBUS; i++) {
         if (b->d_bus[i]) (void)hipFree(b->d_bus[i]);
         if (b->ev_kernel[i]) (void)hipEventDestroy(b->ev_kernel[i]);
         if (b->ev_comm[i]) (void)hipEventDestroy(b->ev_comm[i]);
     }
     if (b->h_bus) (void)hipHostFree(b->h_bus);
-    if (b->h_stage) (void)hipHostFree(b->h_stage);
     for (int i = 0; i < 2; i++) {
         if (b->h_pipe[i]) (void)hipHostFree(b->h_pipe[i]);
         if (b->ev_pipe[i]) (void)hipEventDestroy(b->ev_pipe[i]);
@@ -219,18 +212,30 @@ extern "C" void smx_bank_destroy(smx_bank *b)
 
 extern "C" uint32_t smx_bank_voices(const smx_bank *b) { return b ? b->n : 0; }
 
+// state0 += elapsed * inc for every voice, elapsed = 0: the stored phases are current again.
+static int bank_materialize(smx_bank *b)
+{
+    if (b->elapsed) {
+        int rv = smx::launch_saw_materialize(b->d_inc, b->d_state0, b->n_pad, b->elapsed, b->stream);
+        if (rv) return rv;
+        b->elapsed = 0;
+    }
+    return SMX_OK;
+}
+
 extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *state)
 {
     if (!b) { set_error("smx_bank_load: null bank"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
+    int rv = bank_materialize(b);            // an array that is not replaced keeps its meaning
+    if (rv) return rv;
     SMX_HIP(hipStreamSynchronize(b->stream));
-    b->stage_pos = 0;
     if (inc) {
         SMX_HIP(hipMemcpy(b->d_inc, inc, (size_t)b->n * 4, hipMemcpyHostToDevice));
         b->free_map.load(inc, b->n);
     }
     if (state)
-        SMX_HIP(hipMemcpy(b->d_state[b->cur], state, (size_t)b->n * 4, hipMemcpyHostToDevice));
+        SMX_HIP(hipMemcpy(b->d_state0, state, (size_t)b->n * 4, hipMemcpyHostToDevice));
     return SMX_OK;
 }
 
@@ -238,25 +243,25 @@ extern "C" int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state)
 {
     if (!b) { set_error("smx_bank_read: null bank"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
+    if (state) {
+        int rv = bank_materialize(b);
+        if (rv) return rv;
+    }
     SMX_HIP(hipStreamSynchronize(b->stream));
     if (inc) SMX_HIP(hipMemcpy(inc, b->d_inc, (size_t)b->n * 4, hipMemcpyDeviceToHost));
-    if (state) SMX_HIP(hipMemcpy(state, b->d_state[b->cur], (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    if (state) SMX_HIP(hipMemcpy(state, b->d_state0, (size_t)b->n * 4, hipMemcpyDeviceToHost));
     return SMX_OK;
 }
 
-// One voice's increment changes: a 4-byte async copy from a pinned ring slot, ordered on the
-// bank's stream before the next block's kernel.  No host sync per event: the JACK thread can
-// apply a burst of MIDI events and launch the block right behind them.
+// One voice's increment changes: a one-lane kernel on the bank's stream, ordered before the
+// next block, that also rebases the voice's stored phase so that state0 + elapsed*inc stays
+// continuous ("note_on does not reset the phase", linux/synth.c:156-160).  No host sync per
+// event: the JACK thread can apply a burst of MIDI events and launch the block behind them.
 static int bank_set_inc(smx_bank *b, uint32_t v, uint32_t inc)
 {
     SMX_HIP(hipSetDevice(b->device));
-    if (b->stage_pos == smx_bank::STAGE_SLOTS) {            // ring full: let the copies drain
-        SMX_HIP(hipStreamSynchronize(b->stream));
-        b->stage_pos = 0;
-    }
-    uint32_t *slot = b->h_stage + b->stage_pos++;
-    *slot = inc;
-    SMX_HIP(hipMemcpyAsync(b->d_inc + v, slot, 4, hipMemcpyHostToDevice, b->stream));
+    int rv = smx::launch_saw_rebase(b->d_inc, b->d_state0, v, inc, b->elapsed, b->stream);
+    if (rv) return rv;
     b->free_map.set_free(v, inc == 0);
     return SMX_OK;
 }
@@ -330,12 +335,12 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
     int bi, bnext;
     rv = bank_bus_advance(b, (uint32_t)n, &bi, &bnext);
     if (rv) return rv;
-    rv = smx::launch_saw_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1], b->d_bus[bi],
-                              b->d_bus[bnext], b->n_pad, (uint32_t)n, b->d_scratch, b->stream);
+    rv = smx::launch_saw_bank(b->d_inc, b->d_state0, b->d_bus[bi], b->d_bus[bnext], b->n_pad, (uint32_t)n,
+                              b->elapsed, b->d_scratch, b->stream);
     if (rv) return rv;
+    b->elapsed += (uint32_t)n;             // mod 2^32, like the phases
     b->bus_zeroed[bi] = 0;                 // now holds this block's sums
     b->bus_zeroed[bnext] = (uint32_t)n;    // cleared by the launch
-    b->cur ^= 1;
     b->bus_cur = bi;
     return SMX_OK;
 }
@@ -357,7 +362,6 @@ extern "C" int smx_bank_sync(smx_bank *b)
     if (!b) return SMX_E_ARG;
     SMX_HIP(hipSetDevice(b->device));
     SMX_HIP(hipStreamSynchronize(b->stream));
-    b->stage_pos = 0;
     if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
     return SMX_OK;
 }
@@ -454,10 +458,10 @@ extern "C" int smx_bank_run_square(smx_bank *b, float *vec, int n)
     if (rv) return rv;
     SMX_HIP(hipMemsetAsync(b->d_bus[bi], 0, (size_t)n * 4, b->stream));
     b->bus_zeroed[bi] = 0;
-    rv = smx::launch_square_bank(b->d_inc, b->d_state[b->cur], b->d_state[b->cur ^ 1],
-                                 (uint32_t *)b->d_bus[bi], b->n_pad, (uint32_t)n, b->stream);
+    rv = smx::launch_square_bank(b->d_inc, b->d_state0, (uint32_t *)b->d_bus[bi], b->n_pad, (uint32_t)n,
+                                 b->elapsed, b->stream);
     if (rv) return rv;
-    b->cur ^= 1;
+    b->elapsed += (uint32_t)n;
     b->bus_cur = bi;
     SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
     SMX_HIP(hipStreamSynchronize(b->stream));

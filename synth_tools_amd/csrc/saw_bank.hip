@@ -11,14 +11,20 @@
 // inc[]/state[] so a wave's load is one contiguous 256 B / 1 KiB segment).
 // A lane keeps its voices' phase in registers for the whole block of frames
 // and TC per-frame partial sums in VGPRs; HBM is touched once per voice per
-// block (8 B read, 4 B write).  The block's partial sums go through an LDS
+// block (8 B read, nothing written).  The block's partial sums go through an LDS
 // [TC][64+1] matrix (conflict-free ds_add, padded rows), are folded by a
 // 4-lane shuffle and leave the CU as one integer atomic per frame.
 //
-// Time is split into chunks of 64 frames on blockIdx.y: the phasor is linear,
-// state(t0) = state + t0*inc (mod 2^32), so chunks are independent and small
-// banks still fill the chip.  State is ping-ponged (state_in -> state_out) so
-// that chunks never read what another chunk has already advanced.
+// The phasor is linear, state(t) = state0 + t*inc (mod 2^32), and the kernels use that twice:
+//  * Time is split into chunks of 64 frames on blockIdx.y (state at chunk start in closed
+//    form), so chunks are independent and small banks still fill the chip.
+//  * The advanced phase is never written back.  HBM keeps state0[] and the bank keeps one
+//    counter T of frames elapsed since state0 was valid; a launch reads inc[] and state0[]
+//    (8 B per voice) and starts every voice at state0 + T*inc.  A block therefore moves 8
+//    instead of 12 bytes per voice and is a pure read stream.  The phase is materialised
+//    (state0 += T*inc, T = 0) only when the host reads or reloads the bank, and a note
+//    event rebases one voice: state0 += T*(inc_old - inc_new) (saw_rebase_kernel), which
+//    keeps state0 + T*inc continuous -- the reference's "note_on does not reset the phase".
 //
 // Long blocks of big banks (> 16 frames, >= 2^31 voice-samples) take a second formulation
 // (saw_bank_carry_kernel) that needs 2 instead of 2.5 vector ops per voice-sample:
@@ -58,17 +64,18 @@ __device__ __forceinline__ void stream_store(T v, T *p)
 template <int TC, int VW, bool NT>
 __global__ __launch_bounds__(256)
 void saw_bank_kernel(const uint32_t *__restrict__ inc,
-                     const uint32_t *__restrict__ st_in,
-                     uint32_t *__restrict__ st_out,
+                     const uint32_t *__restrict__ st_in,   // state0[]
                      int32_t *__restrict__ bus,
                      int32_t *__restrict__ bus_next,   // zeroed here for the NEXT launch
                      uint32_t ngroups,      // n_pad / VW
-                     uint32_t nframes)      // total frames of this block
+                     uint32_t nframes,      // total frames of this block
+                     uint32_t tbase)        // frames elapsed since state0 was valid
 {
     __shared__ int32_t M[TC][65];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
-    const uint32_t t0 = blockIdx.y * 64u;   // >0 only when TC == 64
+    const uint32_t t0 = tbase + blockIdx.y * 64u;   // phase offset of this chunk
+    const uint32_t f0 = blockIdx.y * 64u;           // first frame of this chunk (>0 only when TC == 64)
 
     for (uint32_t i = tid; i < TC * 65; i += 256) (&M[0][0])[i] = 0;
     // the bus is accumulated with atomics, so it must start at zero: each launch
@@ -102,23 +109,11 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
             const uint32_t rn = min(gi + gridDim.x, nrows - 1) * 256u + tid;   // last trip re-reads its row
             a_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + rn);
             b_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + rn);
-            asm volatile("" ::: "memory");      // keep the store below the youngest memory operation
             vi[0] = a.x; vi[1] = a.y; vi[2] = a.z; vi[3] = a.w;
             vs[0] = b.x; vs[1] = b.y; vs[2] = b.z; vs[3] = b.w;
         } else {
             vi[0] = stream_load<NT>(inc + g);
             vs[0] = stream_load<NT>(st_in + g);
-        }
-        if (blockIdx.y == 0) {
-            // final state in closed form; inc == 0 leaves the phase untouched
-            if constexpr (VW == 4) {
-                u32x4 o;
-                o.x = vs[0] + nframes * vi[0]; o.y = vs[1] + nframes * vi[1];
-                o.z = vs[2] + nframes * vi[2]; o.w = vs[3] + nframes * vi[3];
-                stream_store<NT>(o, reinterpret_cast<u32x4 *>(st_out) + g);
-            } else {
-                stream_store<NT>(vs[0] + nframes * vi[0], st_out + g);
-            }
         }
 #pragma unroll
         for (int k = 0; k < VW; k++) {
@@ -152,7 +147,7 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
-    if (q == 0 && t < TC && t0 + t < nframes) atomicAdd(&bus[t0 + t], s);
+    if (q == 0 && t < TC && f0 + t < nframes) atomicAdd(&bus[f0 + t], s);
 }
 
 // ---------------------------------------------------------------------------
@@ -194,22 +189,18 @@ __device__ __forceinline__ uint32_t carry_step4(uint32_t &u0, uint32_t &u1, uint
 #endif
 }
 
-// MULTI: more than one 64-frame chunk per launch (blockIdx.y); only chunk 0 writes the
-// advanced phases.  The single-chunk form keeps its memory operations in straight-line
-// order (load, load, store) so that the wait for the prefetched loads is vmcnt(1) and the
-// store's completion is never waited for inside the loop.
+// MULTI: more than one 64-frame chunk per launch (blockIdx.y).
 // TC: frames computed per chunk (64, or 32 for single-chunk blocks of 17..32 frames).
 template <bool NT, bool MULTI, int TC>
 __global__ __launch_bounds__(256)
 void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
-                           uint32_t *__restrict__ st_out, SawPartial *__restrict__ partial,
-                           uint32_t ngroups, uint32_t nframes)
+                           SawPartial *__restrict__ partial, uint32_t ngroups, uint32_t tbase)
 {
     __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
     __shared__ unsigned long long S[2];            // U0, I
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t t0 = blockIdx.y * 64u;
+    const uint32_t t0 = tbase + (MULTI ? blockIdx.y * 64u : 0u);   // phase offset of this chunk
     for (uint32_t i = tid; i < 64 * 65; i += 256) (&M[0][0])[i] = 0;
     H[tid] = 0;
     if (tid < 2) S[tid] = 0;
@@ -242,10 +233,6 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         const uint32_t rn = min(row + gridDim.x, nrows - 1) * 256u + tid;
         a_next = stream_load<NT>(inc4 + rn);
         b_next = stream_load<NT>(st4 + rn);
-        // keep the store the YOUNGEST memory operation of the trip (vmcnt retires in order)
-        asm volatile("" ::: "memory");
-        if (!MULTI || blockIdx.y == 0)
-            stream_store<NT>(b + nframes * a, reinterpret_cast<u32x4 *>(st_out) + g);
         // an inactive voice (inc == 0) is parked at phase 0: it contributes (0 >> 4) = 0
         uint32_t u0 = (a.x ? b.x + t0 * a.x : 0u) ^ 0x80000000u;
         uint32_t u1 = (a.y ? b.y + t0 * a.y : 0u) ^ 0x80000000u;
@@ -361,18 +348,16 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
 __global__ __launch_bounds__(256)
 void square_bank_kernel(const uint32_t *__restrict__ inc,
                         const uint32_t *__restrict__ st_in,
-                        uint32_t *__restrict__ st_out,
                         uint32_t *__restrict__ or_bus,
-                        uint32_t n_pad, uint32_t nframes)
+                        uint32_t n_pad, uint32_t nframes, uint32_t tbase)
 {
-    const uint32_t t0 = blockIdx.y * 64u;
-    const uint32_t nf = min(64u, nframes - t0);
+    const uint32_t f0 = blockIdx.y * 64u;
+    const uint32_t t0 = tbase + f0;
+    const uint32_t nf = min(64u, nframes - f0);
     unsigned long long any_lo = 0;   // bit t: some active voice negative at t0+t
     for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < n_pad; v += gridDim.x * 256u) {
         const uint32_t i = inc[v];
-        const uint32_t s0 = st_in[v];
-        if (blockIdx.y == 0) st_out[v] = s0 + nframes * i;
-        uint32_t s = s0 + t0 * i;
+        uint32_t s = st_in[v] + t0 * i;
         if (i) {
             for (uint32_t t = 0; t < nf; t++) {
                 any_lo |= (unsigned long long)(s >> 31) << t;
@@ -384,24 +369,45 @@ void square_bank_kernel(const uint32_t *__restrict__ inc,
     for (int o = 32; o > 0; o >>= 1) any_lo |= __shfl_xor(any_lo, o);
     if ((threadIdx.x & 63) == 0) {
         for (uint32_t t = 0; t < nf; t++)
-            if ((any_lo >> t) & 1) atomicOr(&or_bus[t0 + t], 0x80000000u);
+            if ((any_lo >> t) & 1) atomicOr(&or_bus[f0 + t], 0x80000000u);
     }
 }
 
-// Grid: persistent workgroups, grid-stride over voices.  In the HBM-bound regime
-// (few frames per launch) 2 workgroups per CU stream fastest (measured: 768 x 256
-// threads = 6.2 TB/s vs 5.6 TB/s at 2048); the VALU-bound regime wants every SIMD full.
+// Lazy state maintenance (see the header comment).
+// A note event on one voice at elapsed time T: keep state0 + T*inc continuous.
+__global__ void saw_rebase_kernel(uint32_t *__restrict__ inc, uint32_t *__restrict__ state0,
+                                  uint32_t voice, uint32_t new_inc, uint32_t tbase)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const uint32_t old = inc[voice];
+        state0[voice] += tbase * (old - new_inc);
+        inc[voice] = new_inc;
+    }
+}
+// Materialise every phase: state0 += T*inc (the host then resets T to 0).
+__global__ __launch_bounds__(256)
+void saw_materialize_kernel(const uint32_t *__restrict__ inc, uint32_t *__restrict__ state0,
+                            uint32_t n_pad, uint32_t tbase)
+{
+    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < n_pad; v += gridDim.x * 256u)
+        state0[v] += tbase * inc[v];
+}
+
+// Grid: persistent workgroups, grid-stride over voices.  The pure read stream of a few-frame
+// block runs fastest with 3-4 workgroups per CU (measured at 64 Mi voices, 1 frame: 768-1024
+// workgroups 6.8 TB/s, 512: 6.3, 2048: 6.0); from 8 frames up the arithmetic wants every
+// SIMD full.
 static uint32_t grid_cap(uint32_t tc, uint32_t gy)
 {
     static const char *env = getenv("SMX_SAW_GRID");      // tuning override
-    uint32_t cap = env ? (uint32_t)atoi(env) : (tc <= 16 ? 768u : 2048u);
+    uint32_t cap = env ? (uint32_t)atoi(env) : (tc <= 4 ? 1024u : 2048u);
     cap = (cap + gy - 1) / gy;
     return cap < 1 ? 1 : cap;
 }
 
 template <int TC, int VW, bool NT>
-int launch_tc(const uint32_t *inc, const uint32_t *si, uint32_t *so, int32_t *bus, int32_t *bus_next,
-              uint32_t n_pad, uint32_t nframes, hipStream_t stream)
+int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bus_next,
+              uint32_t n_pad, uint32_t nframes, uint32_t tbase, hipStream_t stream)
 {
     const uint32_t ngroups = n_pad / VW;
     uint32_t gx = (ngroups + 255) / 256;
@@ -409,22 +415,22 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, uint32_t *so, int32_t *bu
     const uint32_t cap = grid_cap(TC, gy);
     if (gx > cap) gx = cap;
     hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT>), dim3(gx, gy), dim3(256), 0, stream,
-                       inc, si, so, bus, bus_next, ngroups, nframes);
+                       inc, si, bus, bus_next, ngroups, nframes, tbase);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
 
 template <int VW, bool NT>
-int launch_vw(const uint32_t *inc, const uint32_t *si, uint32_t *so, int32_t *bus, int32_t *bus_next,
-              uint32_t n_pad, uint32_t nframes, hipStream_t stream)
+int launch_vw(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bus_next,
+              uint32_t n_pad, uint32_t nframes, uint32_t tbase, hipStream_t stream)
 {
-    if (nframes > 32) return launch_tc<64, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
-    if (nframes > 16) return launch_tc<32, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
-    if (nframes > 8)  return launch_tc<16, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
-    if (nframes > 4)  return launch_tc<8, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
-    if (nframes > 2)  return launch_tc<4, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
-    if (nframes > 1)  return launch_tc<2, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
-    return launch_tc<1, VW, NT>(inc, si, so, bus, bus_next, n_pad, nframes, stream);
+    if (nframes > 32) return launch_tc<64, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
+    if (nframes > 16) return launch_tc<32, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
+    if (nframes > 8)  return launch_tc<16, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
+    if (nframes > 4)  return launch_tc<8, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
+    if (nframes > 2)  return launch_tc<4, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
+    if (nframes > 1)  return launch_tc<2, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
+    return launch_tc<1, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
 }
 
 }  // namespace
@@ -436,9 +442,9 @@ size_t saw_scratch_bytes(uint32_t max_frames)
     return (size_t)SAW_SLOTS * ((max_frames + 63) / 64 + 1) * sizeof(SawPartial);
 }
 
-int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
-                    uint32_t *d_state_out, int32_t *d_bus, int32_t *d_bus_next,
-                    uint32_t n_pad, uint32_t nframes, void *d_scratch, hipStream_t stream)
+int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *d_bus,
+                    int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
+                    void *d_scratch, hipStream_t stream)
 {
     if (n_pad == 0 || (n_pad & 1023) || nframes == 0) {
         set_error("launch_saw_bank: n_pad=%u nframes=%u", n_pad, nframes);
@@ -463,7 +469,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
             auto *part = static_cast<SawPartial *>(d_scratch);     // all zero between launches
 #define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_)                                                             \
     hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_>), dim3(gx, gy), dim3(256), 0, stream, \
-                       d_inc, d_state_in, d_state_out, part, ngroups, nframes)
+                       d_inc, d_state_in, part, ngroups, tbase)
             const bool nt = n_pad >= (1u << 24);
             if (gy > 1)             { if (nt) SMX_CARRY_LAUNCH(true, true, 64);  else SMX_CARRY_LAUNCH(false, true, 64); }
             else if (nframes > 32)  { if (nt) SMX_CARRY_LAUNCH(true, false, 64); else SMX_CARRY_LAUNCH(false, false, 64); }
@@ -479,15 +485,14 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
     // non-temporal streaming once the bank (12 B/voice) cannot live in the 256 MiB
     // Infinity Cache between launches anyway
     if (n_pad >= (1u << 24))
-        return launch_vw<4, true>(d_inc, d_state_in, d_state_out, d_bus, d_bus_next, n_pad, nframes, stream);
+        return launch_vw<4, true>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, stream);
     if (n_pad >= (1u << 20))
-        return launch_vw<4, false>(d_inc, d_state_in, d_state_out, d_bus, d_bus_next, n_pad, nframes, stream);
-    return launch_vw<1, false>(d_inc, d_state_in, d_state_out, d_bus, d_bus_next, n_pad, nframes, stream);
+        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, stream);
+    return launch_vw<1, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, stream);
 }
 
-int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
-                       uint32_t *d_state_out, uint32_t *d_or_bus, uint32_t n_pad,
-                       uint32_t nframes, hipStream_t stream)
+int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in, uint32_t *d_or_bus,
+                       uint32_t n_pad, uint32_t nframes, uint32_t tbase, hipStream_t stream)
 {
     if (n_pad == 0 || (n_pad & 1023) || nframes == 0) return SMX_E_ARG;
     uint32_t gx = n_pad / 256;
@@ -495,7 +500,25 @@ int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
     const uint32_t cap = (2048 + gy - 1) / gy;
     if (gx > cap) gx = cap;
     hipLaunchKernelGGL(square_bank_kernel, dim3(gx, gy), dim3(256), 0, stream,
-                       d_inc, d_state_in, d_state_out, d_or_bus, n_pad, nframes);
+                       d_inc, d_state_in, d_or_bus, n_pad, nframes, tbase);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_saw_rebase(uint32_t *d_inc, uint32_t *d_state0, uint32_t voice, uint32_t new_inc,
+                      uint32_t tbase, hipStream_t stream)
+{
+    hipLaunchKernelGGL(saw_rebase_kernel, dim3(1), dim3(64), 0, stream, d_inc, d_state0, voice, new_inc, tbase);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_saw_materialize(const uint32_t *d_inc, uint32_t *d_state0, uint32_t n_pad, uint32_t tbase,
+                           hipStream_t stream)
+{
+    uint32_t gx = n_pad / 256;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(saw_materialize_kernel, dim3(gx), dim3(256), 0, stream, d_inc, d_state0, n_pad, tbase);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

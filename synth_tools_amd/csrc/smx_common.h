@@ -37,18 +37,23 @@ void set_error(const char *fmt, ...);
 static inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 
 // ---- kernel launchers (defined in the .hip files) --------------------------
-// Saw bank (saw_bank.hip).  n_pad is a multiple of 1024; d_bus[0..nframes) must be zero
-// on entry; the launch zeroes d_bus_next[0..nframes) for its successor.
-// d_scratch: saw_scratch_bytes(max frames) bytes of ZEROED device memory (partial-sum slots
-// of the carry formulation; each launch leaves them zero again), or NULL to force the
-// direct formulation.
+// Saw bank (saw_bank.hip).  n_pad is a multiple of 1024.  HBM holds inc[] and state0[];
+// tbase = frames elapsed since state0 was valid (phase = state0 + tbase*inc): a launch only
+// reads.  d_bus[0..nframes) must be zero on entry; the launch zeroes d_bus_next[0..nframes)
+// for its successor.  d_scratch: saw_scratch_bytes(max frames) bytes of ZEROED device memory
+// (partial-sum slots of the carry formulation; each launch leaves them zero again), or NULL
+// to force the direct formulation.
 size_t saw_scratch_bytes(uint32_t max_frames);
-int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
-                    uint32_t *d_state_out, int32_t *d_bus, int32_t *d_bus_next,
-                    uint32_t n_pad, uint32_t nframes, void *d_scratch, hipStream_t stream);
-int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in,
-                       uint32_t *d_state_out, uint32_t *d_or_bus, uint32_t n_pad,
-                       uint32_t nframes, hipStream_t stream);
+int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state0, int32_t *d_bus,
+                    int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
+                    void *d_scratch, hipStream_t stream);
+int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state0, uint32_t *d_or_bus,
+                       uint32_t n_pad, uint32_t nframes, uint32_t tbase, hipStream_t stream);
+// one voice's increment changes at elapsed time tbase; state0 += tbase*inc for all voices
+int launch_saw_rebase(uint32_t *d_inc, uint32_t *d_state0, uint32_t voice, uint32_t new_inc,
+                      uint32_t tbase, hipStream_t stream);
+int launch_saw_materialize(const uint32_t *d_inc, uint32_t *d_state0, uint32_t n_pad, uint32_t tbase,
+                           hipStream_t stream);
 // Carry-out PDM bank (pdm_bank.hip).  n_pad multiple of 1024; d_bits rows are n_pad/8 bytes.
 int launch_pdm_bank(const uint32_t *d_setpoint, uint32_t *d_accu,
                     const uint32_t *d_dither /*nullable*/, uint32_t *d_bits,
