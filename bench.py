@@ -100,6 +100,37 @@ def cpu_baseline_saw(inc, state, frames, budget_s):
              "sample": "same bank split over %d threads, partial buses (baseline-parallel, not reference behaviour)" % cores})
 
 
+def cpu_baselines_extra(synthetic, tab, budget_s=2.0):
+    """BASELINE.md §3 rows B1 and B4 on one core: the reference's own operating point (64 voices,
+    64-frame blocks) and the carry-out PDM loop (dither 0) on 65 536 channels."""
+    import oracle
+    orc = oracle.load()
+    out = []
+    inc = tab[30:94].astype(np.uint32).copy()                    # notes 30..93 all on
+    st = np.zeros(64, np.uint32)
+    bus = np.zeros(64, np.int32)
+    t0, blocks = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        for _ in range(2000):
+            orc.orc_synth_run(inc, st, 64, None, bus.ctypes.data, 64)
+        blocks += 2000
+    dt = time.perf_counter() - t0
+    out.append({"workload": "B1: reference operating point, 64 voices x 64-frame blocks (linux/synth.c), 1 core",
+                "value": round(64 * 64 * blocks / dt / 1e9, 4), "unit": "Gsamples/s", "cores": 1, "kind": "port"})
+    sp, ac = synthetic.pdm_bank(65536, 0x5EED0003)
+    words = 65536 // 32
+    bits = np.zeros(64 * words, np.uint32)
+    t0, ticks = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        orc.orc_pdm_run(sp, ac, 65536, None, 64, bits)
+        ticks += 64
+    dt = time.perf_counter() - t0
+    out.append({"workload": "B4: carry-out PDM bank (mod_pdm.c), 65536 channels, dither 0, 1 core",
+                "value": round(65536 * ticks / dt / 1e9, 4), "unit": "Gsamples/s (channel-ticks)", "cores": 1,
+                "kind": "port"})
+    return out
+
+
 def time_saw(sta, bank, frames, steps, warmup, comm=False):
     for _ in range(warmup):
         bank.run_async(frames)
@@ -315,6 +346,7 @@ def main():
             single, par = cpu_baseline_saw(inc, state, a.frames, a.cpu_seconds)
             line["cpu_baseline"] = single
             line["cpu_baseline_parallel"] = par
+            line["cpu_baselines_extra"] = cpu_baselines_extra(synthetic, tab)
         if world == 1 and not a.no_also:
             line["also"] = also_workloads(sta, synthetic, tab, bank, a.voices)
         sys.stdout.flush()
