@@ -263,6 +263,15 @@ def test_randomised_block_sequences(smx, orc, inc_table):
                     msg = np.array([0x90, int(rng.integers(0, 128)), int(rng.integers(0, 2)) * 64], np.uint8)
                     bank.midi_event(msg)
                     orc.orc_midi_event(n2v, inc, n, msg, 3)
+            r = rng.random()
+            if r < 0.2:                                        # bulk reload of the increments only
+                inc = np.ascontiguousarray(np.roll(inc, 1))
+                bank.load(inc=inc)
+            elif r < 0.3:                                      # bulk reload of the phases only
+                st = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+                bank.load(state=st)
+            elif r < 0.4:                                      # read-back in the middle (materialises)
+                assert np.array_equal(bank.read()[1], st)
             bus, vec = bank.run(nf)
             obus, ovec = oracle.synth_run(orc, inc, st, nf)
             assert np.array_equal(bus, obus), "n=%d nf=%d" % (n, nf)
