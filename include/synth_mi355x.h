@@ -19,6 +19,10 @@
  *    smx_last_error() gives the text.  There is NO CPU fallback: with no
  *    usable GPU every compute call fails with SMX_E_NOGPU.
  *  - Integer results are bit-exact with the reference CPU loops.
+ *  - Threading: like the reference (everything runs on the JACK RT thread,
+ *    linux/synth.c:277-282), a handle is used by one thread at a time; distinct
+ *    handles are independent.  The reference-named drop-in calls serialise on
+ *    an internal lock.
  */
 #ifndef SYNTH_MI355X_H
 #define SYNTH_MI355X_H

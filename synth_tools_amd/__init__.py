@@ -209,9 +209,9 @@ class SawBank:
         self.n = n_voices
 
     def close(self):
-        if self._h:
-            lib().smx_bank_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.smx_bank_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
@@ -299,9 +299,9 @@ class PdmBank:
         self.words = (n_channels + 31) // 32
 
     def close(self):
-        if self._h:
-            lib().smx_pdm_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.smx_pdm_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
@@ -354,9 +354,9 @@ class PolyBank:
         self.n = n_voices
 
     def close(self):
-        if self._h:
-            lib().smx_poly_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.smx_poly_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
@@ -415,9 +415,9 @@ class PwmBank:
         _check(lib().smx_pwm_config(self._h, control_div_log, out_shift), "smx_pwm_config")
 
     def close(self):
-        if self._h:
-            lib().smx_pwm_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.smx_pwm_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
@@ -487,9 +487,9 @@ class OscBank:
         self.words = (n + 31) // 32
 
     def close(self):
-        if self._h:
-            lib().smx_osc_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.smx_osc_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
@@ -557,12 +557,12 @@ class Firmware:
             self.osc._h, self.osc.n, self.osc.words = lib().smx_fw_osc(self._h), n_oscillators, (n_oscillators + 31) // 32
 
     def close(self):
-        if self._h:
-            self.pwm._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            self.pwm._h = None               # borrowed handles die with the firmware object
             if self.osc:
                 self.osc._h = None
-            lib().smx_fw_destroy(self._h)
-            self._h = None
+            _lib.smx_fw_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
@@ -610,9 +610,9 @@ class CprocBank:
         self.n, self.n_nodes, self.n_inputs = n_instances, len(nodes), n_inputs
 
     def close(self):
-        if self._h:
-            lib().smx_cproc_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.smx_cproc_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
@@ -642,9 +642,9 @@ class ClockBank:
         self.n, self.words = n, (n + 31) // 32
 
     def close(self):
-        if self._h:
-            lib().smx_clock_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.smx_clock_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
