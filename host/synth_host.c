@@ -17,6 +17,7 @@
  *   synth.dynamic.host.elf                       real JACK, 64-voice drop-in path
  *   SYNTH_VOICES=1048576 synth.dynamic.host.elf  real JACK, N-voice bank path
  *   SYNTH_PIPELINE=1 ...                         bank path returns block k-1 while k computes
+ *   SYNTH_FAKE_PERIOD_US=1333 ... --fake-jack    pace the scripted callbacks like a sound card
  *   synth.dynamic.host.elf --fake-jack NBLOCKS NFRAMES EVENTS.bin OUT.f32
  *       EVENTS.bin: records {u32 block; u8 size; u8 bytes[3]} delivered to
  *       midi_in at the start of that block; OUT.f32: NBLOCKS*NFRAMES floats.
@@ -29,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "synth_mi355x.h"
@@ -154,6 +156,13 @@ int main(int argc, char **argv) {
         synth_init(&synth);
         FILE *out = fopen(argv[5], "wb");
         ASSERT(out);
+        double t_sum = 0, t_max = 0;                  /* wall time of process() per block */
+        /* SYNTH_FAKE_PERIOD_US: pace the callbacks like a sound card would (e.g. 1333 for
+           64 frames at 48 kHz); unset = back to back */
+        const char *per = getenv("SYNTH_FAKE_PERIOD_US");
+        const long period_ns = per ? strtol(per, NULL, 0) * 1000L : 0;
+        struct timespec next;
+        clock_gettime(CLOCK_MONOTONIC, &next);
         for (fake.block = 0; fake.block < nblocks; fake.block++) {
             fake.ncur = 0;
             while (fake.cursor < fake.nev && fake.ev[fake.cursor].block == fake.block && fake.ncur < 1024) {
@@ -163,11 +172,23 @@ int main(int argc, char **argv) {
                 fake.cur[fake.ncur].buffer = e->bytes;
                 fake.ncur++;
             }
+            struct timespec ta, tb;
+            if (period_ns) {
+                next.tv_nsec += period_ns;
+                while (next.tv_nsec >= 1000000000L) { next.tv_nsec -= 1000000000L; next.tv_sec++; }
+                clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &next, NULL);
+            }
+            clock_gettime(CLOCK_MONOTONIC, &ta);
             ASSERT(0 == process(nframes, NULL));
+            clock_gettime(CLOCK_MONOTONIC, &tb);
+            double us = (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) * 1e-3;
+            if (fake.block >= 2) { t_sum += us; if (us > t_max) t_max = us; }   /* skip warm-up blocks */
             ASSERT(fwrite(fake.audio, sizeof(float), nframes, out) == nframes);
         }
         fclose(out);
-        LOG("synth: fake-jack rendered %u blocks of %u frames, %u voices\n", nblocks, nframes, voices);
+        LOG("synth: fake-jack rendered %u blocks of %u frames, %u voices; process(): mean %.1f us, max %.1f us "
+            "(deadline at 48 kHz: %.0f us)\n", nblocks, nframes, voices,
+            nblocks > 2 ? t_sum / (nblocks - 2) : 0.0, t_max, nframes / 48000.0 * 1e6);
     } else {
         /* Jack client setup: linux/synth.c:285-301 */
         bind_jack();
