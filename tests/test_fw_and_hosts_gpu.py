@@ -140,3 +140,11 @@ def test_fw_host_port_protocol(orc):
     assert np.array_equal(got, want[:100])
     p.stdin.close()                                          # port_close -> EOF -> exit(1)
     assert p.wait(timeout=30) == 1
+
+
+def test_c_abi_test_program():
+    """tests/c/test_synth_abi.c: plain-C, ASSERT-based, against the shared library."""
+    exe = os.path.join(ROOT, "host", "test_synth_abi.dynamic.host.elf")
+    r = subprocess.run([exe], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stderr.decode().strip().endswith("test_synth_abi.c")
