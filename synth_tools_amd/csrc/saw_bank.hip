@@ -143,6 +143,61 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     if (q == 0 && t < TC && f0 + t < nframes) atomicAdd(&bus[f0 + t], s);
 }
 
+// Few-frame blocks (the tick ABI: 1..4 frames) of banks with >= 2^20 voices: the same direct
+// formulation in 1024-thread workgroups.  A few-frame launch is a pure read stream plus ONE
+// bus atomic per frame per workgroup; big workgroups give the stream the same bytes in flight
+// with a quarter of the workgroups (256 x 1024 threads: 6.9 TB/s), and a quarter of the
+// serialised atomics.  Partial sums are folded with wave shuffles instead of the LDS matrix.
+template <int TC, bool NT>
+__global__ __launch_bounds__(1024)
+void saw_tick_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
+                     int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
+                     uint32_t ngroups, uint32_t nframes, uint32_t tbase)
+{
+    __shared__ int32_t W[16][TC];
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid < nframes) bus_next[tid] = 0;     // same contract as saw_bank_kernel
+    int32_t acc[TC];
+#pragma unroll
+    for (int t = 0; t < TC; t++) acc[t] = 0;
+    const u32x4 *inc4 = reinterpret_cast<const u32x4 *>(inc);
+    const u32x4 *st4 = reinterpret_cast<const u32x4 *>(st_in);
+    const uint32_t nrows = ngroups >> 10;                        // ngroups is a multiple of 1024 here
+    u32x4 a_next = 0, b_next = 0;
+    if (blockIdx.x < nrows) {
+        a_next = stream_load<NT>(inc4 + blockIdx.x * 1024u + tid);
+        b_next = stream_load<NT>(st4 + blockIdx.x * 1024u + tid);
+    }
+    for (uint32_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const u32x4 a = a_next, b = b_next;
+        const uint32_t rn = min(row + gridDim.x, nrows - 1) * 1024u + tid;   // software prefetch
+        a_next = stream_load<NT>(inc4 + rn);
+        b_next = stream_load<NT>(st4 + rn);
+        u32x4 s = b + tbase * a;
+        // an inactive voice (inc == 0) contributes nothing: park it at 0
+        s.x = a.x ? s.x : 0u; s.y = a.y ? s.y : 0u; s.z = a.z ? s.z : 0u; s.w = a.w ? s.w : 0u;
+#pragma unroll
+        for (int t = 0; t < TC; t++) {
+            acc[t] += ((int32_t)s.x >> 4) + ((int32_t)s.y >> 4);
+            acc[t] += ((int32_t)s.z >> 4) + ((int32_t)s.w >> 4);
+            s += a;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TC; t++) {
+        int32_t v = acc[t];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) W[tid >> 6][t] = v;
+    }
+    __syncthreads();
+    if (tid < TC && tid < nframes) {
+        int32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) v += W[w][tid];
+        atomicAdd(&bus[tid], v);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // carry-count formulation (see the header comment)
 // ---------------------------------------------------------------------------
@@ -386,16 +441,23 @@ void saw_materialize_kernel(const uint32_t *__restrict__ inc, uint32_t *__restri
         state0[v] += tbase * inc[v];
 }
 
-// Grid: persistent workgroups, grid-stride over voices.  The pure read stream of a few-frame
-// block runs fastest with 3-4 workgroups per CU (measured at 64 Mi voices, 1 frame: 768-1024
-// workgroups 6.8 TB/s, 512: 6.3, 2048: 6.0); from 8 frames up the arithmetic wants every
-// SIMD full.
-static uint32_t grid_cap(uint32_t tc, uint32_t gy)
+// Grid: persistent workgroups, grid-stride over voices.  Two effects set the size:
+//  * every workgroup ends with one integer atomic per frame on the same bus words, and those
+//    serialise (~20 ns each): a 1 Mi-voice block of 64 frames takes 12.6 us with 256
+//    workgroups and 23 us with 1024.  So a workgroup should own at least 4 rows of 256 lanes;
+//  * the pure read stream of a few-frame block runs fastest with 3-4 workgroups per CU (64 Mi
+//    voices, 1 frame: 768-1024 workgroups 6.8 TB/s, 512: 6.3, 2048: 6.0); from 8 frames up the
+//    arithmetic wants every SIMD full (2048).
+static uint32_t grid_size(uint32_t tc, uint32_t rows, uint32_t gy)
 {
     static const char *env = getenv("SMX_SAW_GRID");      // tuning override
     uint32_t cap = env ? (uint32_t)atoi(env) : (tc <= 4 ? 1024u : 2048u);
     cap = (cap + gy - 1) / gy;
-    return cap < 1 ? 1 : cap;
+    uint32_t gx = rows / 4;
+    if (gx < 128) gx = 128;
+    if (gx > cap) gx = cap;
+    if (gx > rows) gx = rows;
+    return gx < 1 ? 1 : gx;
 }
 
 template <int TC, int VW, bool NT>
@@ -403,10 +465,8 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
               uint32_t n_pad, uint32_t nframes, uint32_t tbase, hipStream_t stream)
 {
     const uint32_t ngroups = n_pad / VW;
-    uint32_t gx = (ngroups + 255) / 256;
     const uint32_t gy = (nframes + 63) / 64;
-    const uint32_t cap = grid_cap(TC, gy);
-    if (gx > cap) gx = cap;
+    const uint32_t gx = grid_size(TC, (ngroups + 255) / 256, gy);
     hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT>), dim3(gx, gy), dim3(256), 0, stream,
                        inc, si, bus, bus_next, ngroups, nframes, tbase);
     SMX_HIP(hipGetLastError());
@@ -473,6 +533,27 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         }
+    }
+    if (nframes <= 4 && n_pad >= (1u << 20) && n_pad < (1u << 26) && (n_pad & 4095) == 0) {
+        // tick ABI on a 2^20..2^26-voice bank: 1024-thread streaming workgroups, >= 4 rows each
+        // (measured: 16 Mi voices 19.6 us vs 27.4 us with 256-thread workgroups; from 64 Mi voices
+        // up the 1024 x 256-thread grid of saw_bank_kernel is 3 % faster)
+        const uint32_t ngroups = n_pad / 4, nrows = ngroups >> 10;
+        static const char *tg = getenv("SMX_SAW_TICK_GRID");           // tuning override
+        uint32_t gx = nrows / 4;
+        const uint32_t cap = tg ? (uint32_t)atoi(tg) : 256u;
+        if (gx > cap) gx = cap;
+        if (gx < 1) gx = 1;
+        const bool nt = n_pad >= (1u << 24);
+#define SMX_TICK_LAUNCH(TC_, NT_)                                                              \
+    hipLaunchKernelGGL((saw_tick_kernel<TC_, NT_>), dim3(gx), dim3(1024), 0, stream, d_inc,    \
+                       d_state_in, d_bus, d_bus_next, ngroups, nframes, tbase)
+        if (nframes == 1)      { if (nt) SMX_TICK_LAUNCH(1, true); else SMX_TICK_LAUNCH(1, false); }
+        else if (nframes == 2) { if (nt) SMX_TICK_LAUNCH(2, true); else SMX_TICK_LAUNCH(2, false); }
+        else                   { if (nt) SMX_TICK_LAUNCH(4, true); else SMX_TICK_LAUNCH(4, false); }
+#undef SMX_TICK_LAUNCH
+        SMX_HIP(hipGetLastError());
+        return SMX_OK;
     }
     // 4 voices per lane once there are enough voices to fill the chip that way;
     // non-temporal streaming once the bank (12 B/voice) cannot live in the 256 MiB
