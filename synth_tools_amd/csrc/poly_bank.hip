@@ -110,8 +110,14 @@ int launch_poly_bank(const PolyArrays &p, int32_t *d_bus_lr, uint32_t n_pad, uin
         set_error("launch_poly_bank: n_pad=%u nframes=%u", n_pad, nframes);
         return SMX_E_ARG;
     }
-    uint32_t gx = n_pad / 256;
+    // ~35 dependent vector ops per voice-sample: parallelism matters more than the serialised
+    // bus atomics at the end (256 Ki voices x 64 frames: 33 us with 512-1024 workgroups, 46 us
+    // with 256); only few-frame blocks prefer fewer, longer workgroups (1 frame: 9.7 vs 17 us).
+    const uint32_t rows = n_pad / 256;
+    uint32_t gx = nframes <= 4 ? rows / 4 : rows;
+    if (gx < 128) gx = 128;
     if (gx > 1024) gx = 1024;                      // 4 workgroups per CU (33 KB LDS each)
+    if (gx > rows) gx = rows;
     hipLaunchKernelGGL(poly_bank_kernel, dim3(gx), dim3(256), 0, stream, p, d_bus_lr, n_pad, nframes);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
