@@ -199,6 +199,19 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
                     "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
                     "ms_per_step": round(ms, 4), "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
                     "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    # the same bank with channel-stream output (no transpose: 2 instead of 3 vector ops per tick)
+    for with_d in (False, True):
+        p.tick_n_streams_async(nt, with_d)
+        p.sync()
+        p.timer_start()
+        for _ in range(5):
+            p.tick_n_streams_async(nt, with_d)
+        ms = p.timer_stop() / 5
+        alg = 12.0 * n + nt * n / 8.0
+        out.append({"workload": "c3: carry-out PDM bank, %d channels, %d ticks/launch, channel-stream layout, dither=%s" % (n, nt, "seeded" if with_d else "0"),
+                    "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
+                    "ms_per_step": round(ms, 4), "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
+                    "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     p.close()
     # noise-shaped PWM bank (mod_pdm_pwm.c: pdm2 + glide + control rate), 1 Mi channels
     n, nt = 1 << 20, 1024

@@ -159,6 +159,13 @@ int smx_pdm_read(smx_pdm *p, uint32_t *setpoint, uint32_t *accu);
  * bit (c&31) of word (c>>5).  Synchronous. */
 int smx_pdm_tick_n(smx_pdm *p, uint32_t n_ticks, const uint32_t *dither,
                    uint32_t *bits);
+/* The same ticks with channel-stream output (what a per-channel decimator or DAC model
+ * reads; the intent of linux/test_pdm.c:1-10): streams[k * n + c], bit j = the pulse of
+ * channel c at tick 32k+j.  n_ticks must be a multiple of 32.  streams: host
+ * uint32[(n_ticks/32) * n] or NULL.  This layout needs no transpose on the GPU (2 instead
+ * of 3 vector ops per channel-tick). */
+int smx_pdm_tick_n_streams(smx_pdm *p, uint32_t n_ticks, const uint32_t *dither, uint32_t *streams);
+int smx_pdm_tick_n_streams_async(smx_pdm *p, uint32_t n_ticks, int with_dither);
 /* Asynchronous, output stays in HBM (smx_pdm_bits_dev). */
 int   smx_pdm_tick_n_async(smx_pdm *p, uint32_t n_ticks, int with_dither);
 void *smx_pdm_bits_dev(smx_pdm *p);

@@ -107,6 +107,8 @@ ABI = [
     ("smx_pdm_read", C.c_int, [_P, _P, _P]),
     ("smx_pdm_tick_n", C.c_int, [_P, C.c_uint32, _P, _P]),
     ("smx_pdm_tick_n_async", C.c_int, [_P, C.c_uint32, C.c_int]),
+    ("smx_pdm_tick_n_streams", C.c_int, [_P, C.c_uint32, _P, _P]),
+    ("smx_pdm_tick_n_streams_async", C.c_int, [_P, C.c_uint32, C.c_int]),
     ("smx_pdm_bits_dev", _P, [_P]),
     ("smx_pdm_dither_dev", _P, [_P, C.c_uint32]),
     ("smx_pdm_sync", C.c_int, [_P]),
@@ -330,6 +332,16 @@ class PdmBank:
 
     def tick_n_async(self, n_ticks, with_dither=False):
         _check(lib().smx_pdm_tick_n_async(self._h, n_ticks, int(with_dither)), "smx_pdm_tick_n_async")
+
+    def tick_n_streams(self, n_ticks, dither=None, want=True):
+        """-> uint32[n_ticks/32, n]: bit j of word [k, c] = pulse of channel c at tick 32k+j."""
+        d = None if dither is None else np.ascontiguousarray(dither, np.uint32)
+        out = np.empty((n_ticks // 32, self.n), np.uint32) if want else None
+        _check(lib().smx_pdm_tick_n_streams(self._h, n_ticks, _ptr(d), _ptr(out)), "smx_pdm_tick_n_streams")
+        return out
+
+    def tick_n_streams_async(self, n_ticks, with_dither=False):
+        _check(lib().smx_pdm_tick_n_streams_async(self._h, n_ticks, int(with_dither)), "smx_pdm_tick_n_streams_async")
 
     def sync(self):
         _check(lib().smx_pdm_sync(self._h), "smx_pdm_sync")

@@ -142,6 +142,37 @@ extern "C" int smx_pdm_tick_n_async(smx_pdm *p, uint32_t n_ticks, int with_dithe
                                 p->d_bits, p->n_pad, p->n, n_ticks, p->stream);
 }
 
+extern "C" int smx_pdm_tick_n_streams_async(smx_pdm *p, uint32_t n_ticks, int with_dither)
+{
+    if (!p) return SMX_E_ARG;
+    if (n_ticks & 31) { set_error("smx_pdm_tick_n_streams: n_ticks=%u is not a multiple of 32", n_ticks); return SMX_E_ARG; }
+    if (n_ticks == 0) return SMX_OK;
+    SMX_HIP(hipSetDevice(p->device));
+    int rv = pdm_ensure(p, n_ticks);                 // same byte count as the tick-major matrix
+    if (rv) return rv;
+    return smx::launch_pdm_streams(p->d_setpoint, p->d_accu, with_dither ? p->d_dither : nullptr, p->d_bits,
+                                   p->n_pad, n_ticks, p->stream);
+}
+
+extern "C" int smx_pdm_tick_n_streams(smx_pdm *p, uint32_t n_ticks, const uint32_t *dither, uint32_t *streams)
+{
+    if (!p) return SMX_E_ARG;
+    if (n_ticks & 31) { set_error("smx_pdm_tick_n_streams: n_ticks=%u is not a multiple of 32", n_ticks); return SMX_E_ARG; }
+    if (n_ticks == 0) return SMX_OK;
+    SMX_HIP(hipSetDevice(p->device));
+    int rv = pdm_ensure(p, n_ticks);
+    if (rv) return rv;
+    if (dither)
+        SMX_HIP(hipMemcpyAsync(p->d_dither, dither, (size_t)n_ticks * 4, hipMemcpyHostToDevice, p->stream));
+    rv = smx_pdm_tick_n_streams_async(p, n_ticks, dither != nullptr);
+    if (rv) return rv;
+    if (streams)
+        SMX_HIP(hipMemcpy2DAsync(streams, (size_t)p->n * 4, p->d_bits, (size_t)p->n_pad * 4, (size_t)p->n * 4,
+                                 n_ticks / 32, hipMemcpyDeviceToHost, p->stream));
+    SMX_HIP(hipStreamSynchronize(p->stream));
+    return SMX_OK;
+}
+
 extern "C" int smx_pdm_sync(smx_pdm *p)
 {
     if (!p) return SMX_E_ARG;

@@ -106,9 +106,86 @@ void pdm_bank_kernel(const uint32_t *__restrict__ setpoint,
     accu[ch] = a;
 }
 
+// ---------------------------------------------------------------------------
+// Channel-stream output: streams[tick/32][channel], bit j of a word = the pulse of that
+// channel at tick 32k+j (what a per-channel decimator or DAC model consumes).  No transpose
+// is needed: a lane shifts its own channel's carry into its own word, w = w + w + carry, one
+// v_addc_co_u32 -- 2 vector ops per channel-tick instead of 3.  Four channels per lane so
+// that every carry mask is consumed >= 3 instructions after the v_add_co that wrote it
+// (gfx950 VALU-SGPR hazard), and so that a lane stores 16 contiguous bytes per 32 ticks.
+// ---------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void stream_step4(u32x4 &a, const u32x4 &x, u32x4 &w)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long m0, m1, m2, m3;
+    asm("v_add_co_u32_e64 %0, %8, %0, %12\n\t"
+        "v_add_co_u32_e64 %1, %9, %1, %13\n\t"
+        "v_add_co_u32_e64 %2, %10, %2, %14\n\t"
+        "v_add_co_u32_e64 %3, %11, %3, %15\n\t"
+        "v_addc_co_u32_e64 %4, vcc, %4, %4, %8\n\t"
+        "v_addc_co_u32_e64 %5, vcc, %5, %5, %9\n\t"
+        "v_addc_co_u32_e64 %6, vcc, %6, %6, %10\n\t"
+        "v_addc_co_u32_e64 %7, vcc, %7, %7, %11"
+        : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w),
+          "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)
+        : "vcc");
+#else
+    (void)a; (void)x; (void)w;
+#endif
+}
+
+template <bool DITHER>
+__global__ __launch_bounds__(256)
+void pdm_stream_kernel(const uint32_t *__restrict__ setpoint, uint32_t *__restrict__ accu,
+                       const uint32_t *__restrict__ dither, uint32_t *__restrict__ streams,
+                       uint32_t ngroups /* n_pad / 4 */, uint32_t nwords /* nticks / 32 */)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= ngroups) return;
+    const u32x4 sp = reinterpret_cast<const u32x4 *>(setpoint)[g];
+    u32x4 a = reinterpret_cast<const u32x4 *>(accu)[g];
+    for (uint32_t k = 0; k < nwords; k++) {
+        u32x4 w = 0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const u32x4 x = DITHER ? sp + dither[k * 32 + j] : sp;
+            stream_step4(a, x, w);
+        }
+        // the oldest tick sits in bit 31: reverse so that bit j is tick 32k+j
+        u32x4 o;
+        o.x = __brev(w.x); o.y = __brev(w.y); o.z = __brev(w.z); o.w = __brev(w.w);
+        reinterpret_cast<u32x4 *>(streams)[(size_t)k * ngroups + g] = o;
+    }
+    reinterpret_cast<u32x4 *>(accu)[g] = a;
+}
+
 }  // namespace
 
 namespace smx {
+
+int launch_pdm_streams(const uint32_t *d_setpoint, uint32_t *d_accu, const uint32_t *d_dither,
+                       uint32_t *d_streams, uint32_t n_pad, uint32_t nticks, hipStream_t stream)
+{
+    if (n_pad == 0 || (n_pad & 1023) || (nticks & 31)) {
+        set_error("launch_pdm_streams: n_pad=%u nticks=%u (multiple of 32)", n_pad, nticks);
+        return SMX_E_ARG;
+    }
+    if (nticks == 0) return SMX_OK;
+    const uint32_t ngroups = n_pad / 4;
+    const dim3 grid((ngroups + 255) / 256), block(256);
+    if (d_dither)
+        hipLaunchKernelGGL(pdm_stream_kernel<true>, grid, block, 0, stream, d_setpoint, d_accu, d_dither,
+                           d_streams, ngroups, nticks / 32);
+    else
+        hipLaunchKernelGGL(pdm_stream_kernel<false>, grid, block, 0, stream, d_setpoint, d_accu, d_dither,
+                           d_streams, ngroups, nticks / 32);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
 
 int launch_pdm_bank(const uint32_t *d_setpoint, uint32_t *d_accu,
                     const uint32_t *d_dither, uint32_t *d_bits, uint32_t n_pad,

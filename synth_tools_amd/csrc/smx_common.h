@@ -59,6 +59,10 @@ int launch_pdm_bank(const uint32_t *d_setpoint, uint32_t *d_accu,
                     const uint32_t *d_dither /*nullable*/, uint32_t *d_bits,
                     uint32_t n_pad, uint32_t n, uint32_t nticks, hipStream_t stream);
 
+// Same ticks, channel-stream output: d_streams[nticks/32][n_pad] (bit j = tick 32k+j).
+int launch_pdm_streams(const uint32_t *d_setpoint, uint32_t *d_accu, const uint32_t *d_dither,
+                       uint32_t *d_streams, uint32_t n_pad, uint32_t nticks, hipStream_t stream);
+
 // Poly voice bank (poly_bank.hip): device SoA arrays, n_pad entries each.
 struct PolyArrays {
     uint32_t *inc, *phase;

@@ -108,3 +108,34 @@ def test_c3_full_size_with_dither(smx, orc):
     assert np.array_equal(bits[:, lo // 32:(lo + 1024) // 32], want)
     assert np.array_equal(gac[lo:lo + 1024], oa)
     bank.close()
+
+
+def _to_streams(bits, n):
+    """tick-major pulse words -> channel streams [ticks/32][n] (numpy reference transform)."""
+    nt = bits.shape[0]
+    b = ((bits[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(nt, -1)[:, :n].astype(np.uint32)   # [tick][channel]
+    b = b.reshape(nt // 32, 32, n)
+    return (b << np.arange(32, dtype=np.uint32)[None, :, None]).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 1025, 3000])
+@pytest.mark.parametrize("with_dither", [False, True])
+def test_channel_stream_layout(smx, orc, n, with_dither):
+    """smx_pdm_tick_n_streams: same pulses as the tick-major matrix, stored per channel."""
+    sp, _ = synthetic.pdm_bank(n, 0x5EED0350 + n)
+    accu = (synthetic.splitmix64(n + 1, n) >> np.uint64(32)).astype(np.uint32)
+    bank = smx.PdmBank(n)
+    bank.load(sp, accu)
+    oa = accu.copy()
+    for k, nt in enumerate([32, 64, 160]):
+        d = synthetic.dither_stream(nt, 2000 + k, 0x0FFFFFFF) if with_dither else None
+        got = bank.tick_n_streams(nt, d)
+        want = _to_streams(oracle.pdm_run(orc, sp, oa, nt, d), n)
+        assert np.array_equal(got, want), "n=%d nt=%d" % (n, nt)
+        if k == 1:                                   # the two layouts share the accumulators
+            got2 = bank.tick_n(40, None)
+            assert np.array_equal(got2, oracle.pdm_run(orc, sp, oa, 40, None))
+    assert np.array_equal(bank.read()[1], oa)
+    with pytest.raises(smx.SmxError):
+        bank.tick_n_streams(33)
+    bank.close()
