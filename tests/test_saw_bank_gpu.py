@@ -326,3 +326,11 @@ def test_dropin_tick_functions(smx, orc):
             got, want = L.sum_tick_saw(C.byref(x)), orc.orc_bus_to_float(orc.orc_sum_tick_saw(inc, st, 64))
         assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32)
     assert [x.voice[v].note_state for v in range(64)] == st.tolist()
+
+
+def test_tick_kernel_1_to_4_frames(smx, orc, inc_table):
+    """<= 4-frame blocks of 2^20..2^26-voice banks (n a multiple of 4096) run saw_tick_kernel
+    (1024-thread workgroups): every frame count 1..4, off voices, repeated ticks."""
+    n = 1 << 21
+    inc, state = synthetic.saw_bank(n, 0x5EED0A11, inc_table, active_fraction=0.85)
+    _check(smx, orc, inc, state, [1, 2, 3, 4, 1, 1, 64, 3])
