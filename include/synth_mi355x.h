@@ -131,7 +131,10 @@ int smx_comm_unique_id(uint8_t id[SMX_UNIQUE_ID_BYTES]);   /* rank 0 */
 int smx_bank_comm_init(smx_bank *b, int rank, int nranks,
                        const uint8_t id[SMX_UNIQUE_ID_BYTES]);
 /* All-reduce (sum, int32) of the last block's bus across ranks, in place in
- * device memory, on a second stream ordered after the block's kernel. */
+ * device memory, on a second stream ordered after the block's kernel.  Requests are
+ * queued and issued as one grouped RCCL launch per 8 blocks (fewer, larger
+ * collectives), or at once when a result is needed (smx_bank_fetch / smx_bank_sync /
+ * pipelined smx_bank_run). */
 int smx_bank_allreduce_async(smx_bank *b, int n);
 /* Copy the (reduced) bus to the host and convert as linux/synth.c:180. */
 int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n);

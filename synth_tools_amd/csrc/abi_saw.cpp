@@ -110,15 +110,28 @@ struct smx_bank {
     hipEvent_t ev_kernel[NBUS] = {};             // kernel of bus[i] finished
     hipEvent_t ev_comm[NBUS] = {};               // all-reduce of bus[i] finished
     bool comm_pending[NBUS] = {};                // an all-reduce was issued on bus[i] and not waited for
+    int ev_owner[NBUS] = {};                     // ev_comm[ev_owner[i]] completes after bus[i]'s all-reduce
+    // All-reduces are requested per block but issued in groups (fewer, larger collectives): a
+    // request is queued and the queue is flushed as ONE grouped RCCL launch when it holds NBUS/2
+    // blocks, or as soon as somebody needs a result (fetch, sync, buffer reuse).
+    int ar_queue[NBUS] = {};                     // bus indices with a requested, not yet issued sum
+    int ar_frames[NBUS] = {};
+    int ar_count = 0;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int note2voice[128];
     smx::FreeMap free_map;
 };
 
+static int bank_comm_flush(smx_bank *b);
+
 static int bank_ensure_bus(smx_bank *b, uint32_t n)
 {
     if (n <= b->bus_cap) return SMX_OK;
+    if (b->comm) {                                   // queued sums refer to the buffers being replaced
+        int rv = bank_comm_flush(b);
+        if (rv) return rv;
+    }
     SMX_HIP(hipStreamSynchronize(b->stream));
     if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
     const uint32_t cap = smx::round_up(n < 4096 ? 4096 : n, 4096);
@@ -292,15 +305,64 @@ extern "C" int smx_bank_note_off(smx_bank *b, int note)
 // runs its all-reduces in order, so waiting for a YOUNGER one covers buffer i too: the wait
 // is taken on the youngest all-reduce that is at least NBUS/2 blocks old, which retires half
 // the ring at once -- one cross-stream barrier per NBUS/2 blocks in steady state.
+#define SMX_NCCL(expr)                                                         \
+    do {                                                                       \
+        ncclResult_t r_ = (expr);                                              \
+        if (r_ != ncclSuccess) {                                               \
+            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
+                      ncclGetErrorString(r_));                                 \
+            return SMX_E_COMM;                                                 \
+        }                                                                      \
+    } while (0)
+
+// Issue every queued bus sum as one grouped RCCL launch on the comm stream, ordered after all
+// kernels enqueued so far.  Integer sums: associative, the same bits in any order.
+static int bank_comm_flush(smx_bank *b)
+{
+    if (b->ar_count == 0) return SMX_OK;
+    const int last = b->ar_queue[b->ar_count - 1];
+    SMX_HIP(hipEventRecord(b->ev_kernel[last], b->stream));
+    SMX_HIP(hipStreamWaitEvent(b->comm_stream, b->ev_kernel[last], 0));
+    SMX_NCCL(ncclGroupStart());
+    for (int k = 0; k < b->ar_count; k++) {
+        const int i = b->ar_queue[k];
+        SMX_NCCL(ncclAllReduce(b->d_bus[i], b->d_bus[i], (size_t)b->ar_frames[k], ncclInt32, ncclSum, b->comm,
+                               b->comm_stream));
+    }
+    SMX_NCCL(ncclGroupEnd());
+    SMX_HIP(hipEventRecord(b->ev_comm[last], b->comm_stream));
+    for (int k = 0; k < b->ar_count; k++) {
+        b->comm_pending[b->ar_queue[k]] = true;
+        b->ev_owner[b->ar_queue[k]] = last;
+    }
+    b->ar_count = 0;
+    return SMX_OK;
+}
+
+static bool bank_ar_queued(const smx_bank *b, int i)
+{
+    for (int k = 0; k < b->ar_count; k++)
+        if (b->ar_queue[k] == i) return true;
+    return false;
+}
+
+// Make the compute stream wait until no all-reduce still uses bus buffer i.  The comm stream
+// runs its all-reduces in order, so waiting for a YOUNGER one covers buffer i too: the wait
+// is taken on the youngest all-reduce that is at least NBUS/2 blocks old, which retires half
+// the ring at once -- one cross-stream barrier per NBUS/2 blocks in steady state.
 static int bank_bus_release(smx_bank *b, int i)
 {
+    if (bank_ar_queued(b, i)) {
+        int rv = bank_comm_flush(b);
+        if (rv) return rv;
+    }
     if (!b->comm_pending[i]) return SMX_OK;
     int j = i;
     for (int k = smx_bank::NBUS / 2 - 1; k > 0; k--) {
         const int c = (i + k) % smx_bank::NBUS;
         if (b->comm_pending[c]) { j = c; break; }
     }
-    SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[j], 0));
+    SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[b->ev_owner[j]], 0));
     for (int c = i;; c = (c + 1) % smx_bank::NBUS) {     // everything from i up to j is now safe
         b->comm_pending[c] = false;
         if (c == j) break;
@@ -361,6 +423,10 @@ extern "C" int smx_bank_sync(smx_bank *b)
 {
     if (!b) return SMX_E_ARG;
     SMX_HIP(hipSetDevice(b->device));
+    if (b->comm) {
+        int rv = bank_comm_flush(b);
+        if (rv) return rv;
+    }
     SMX_HIP(hipStreamSynchronize(b->stream));
     if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
     return SMX_OK;
@@ -371,8 +437,12 @@ extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
     if (!b || n <= 0 || (uint32_t)n > b->bus_cap) { set_error("smx_bank_fetch: bad args"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
     const int bi = b->bus_cur;
+    if (bank_ar_queued(b, bi)) {                   // somebody needs the sum now: issue the group
+        int rv = bank_comm_flush(b);
+        if (rv) return rv;
+    }
     if (b->comm_pending[bi]) {
-        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[b->ev_owner[bi]], 0));
         b->comm_pending[bi] = false;
     }
     SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
@@ -417,8 +487,12 @@ static int bank_run_pipelined(smx_bank *b, float *vec, int32_t *bus, int n)
     if (rv) return rv;
     const int cur = b->pipe_k & 1, prev = cur ^ 1;
     const int bi = b->bus_cur;
+    if (bank_ar_queued(b, bi)) {
+        rv = bank_comm_flush(b);
+        if (rv) return rv;
+    }
     if (b->comm_pending[bi]) {
-        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[b->ev_owner[bi]], 0));
         b->comm_pending[bi] = false;
     }
     SMX_HIP(hipMemcpyAsync(b->h_pipe[cur], b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
@@ -491,16 +565,6 @@ extern "C" int smx_bank_timer_stop(smx_bank *b, float *ms)
 }
 
 // ---- multi-GPU ---------------------------------------------------------------
-#define SMX_NCCL(expr)                                                         \
-    do {                                                                       \
-        ncclResult_t r_ = (expr);                                              \
-        if (r_ != ncclSuccess) {                                               \
-            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
-                      ncclGetErrorString(r_));                                 \
-            return SMX_E_COMM;                                                 \
-        }                                                                      \
-    } while (0)
-
 static_assert(sizeof(ncclUniqueId) == SMX_UNIQUE_ID_BYTES, "ncclUniqueId size");
 
 extern "C" int smx_comm_unique_id(uint8_t id[SMX_UNIQUE_ID_BYTES])
@@ -532,13 +596,11 @@ extern "C" int smx_bank_allreduce_async(smx_bank *b, int n)
     if (!b->comm) { set_error("smx_bank_allreduce_async: smx_bank_comm_init not called"); return SMX_E_STATE; }
     SMX_HIP(hipSetDevice(b->device));
     const int bi = b->bus_cur;
-    SMX_HIP(hipEventRecord(b->ev_kernel[bi], b->stream));
-    SMX_HIP(hipStreamWaitEvent(b->comm_stream, b->ev_kernel[bi], 0));
-    // integer sum: associative, so the result is the same bits in any order
-    SMX_NCCL(ncclAllReduce(b->d_bus[bi], b->d_bus[bi], (size_t)n, ncclInt32, ncclSum, b->comm,
-                           b->comm_stream));
-    SMX_HIP(hipEventRecord(b->ev_comm[bi], b->comm_stream));
-    b->comm_pending[bi] = true;
+    if (bank_ar_queued(b, bi) || b->comm_pending[bi]) return SMX_OK;      // already requested for this block
+    b->ar_queue[b->ar_count] = bi;
+    b->ar_frames[b->ar_count] = n;
+    b->ar_count++;
+    if (b->ar_count >= smx_bank::NBUS / 2) return bank_comm_flush(b);
     return SMX_OK;
 }
 
