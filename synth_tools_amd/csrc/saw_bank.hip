@@ -323,13 +323,17 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         s += __shfl_xor(s, 2);
         if (q == 0) atomicAdd(&out->W[t], s);
     }
-    {   // low-nibble sums per frame from the histogram: 4 lanes x 64 bins per frame
+    {   // low-nibble sums per frame from the histogram: 4 lanes x 64 bins per frame.  A workgroup
+        // sees at most 400 rows x 1024 voices < 2^19 voices (launch_saw_bank), a bin count fits 24
+        // bits and 64 bins x count x 15 < 2^31: 32-bit v_mad_u32_u24 sums, widened at the end.
         const uint32_t t = tid >> 2, q = tid & 3;
-        unsigned long long l = 0;
+        uint32_t l32 = 0;
+#pragma unroll 8
         for (uint32_t k = 0; k < 64; k++) {
             const uint32_t bin = q * 64 + k;
-            l += (unsigned long long)H[bin] * (((bin >> 4) + t * (bin & 15)) & 15);
+            l32 = __umul24(H[bin], ((bin >> 4) + t * (bin & 15)) & 15) + l32;
         }
+        unsigned long long l = l32;
         l += __shfl_xor(l, 1);
         l += __shfl_xor(l, 2);
         if (q == 0) atomicAdd(&out->L[t], l);
