@@ -148,3 +148,22 @@ def test_c_abi_test_program():
     r = subprocess.run([exe], capture_output=True, timeout=120)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stderr.decode().strip().endswith("test_synth_abi.c")
+
+
+def test_c1_one_voice_750_blocks(tmp_path, orc):
+    """BASELINE config 1: 1 voice, note 69, 64-frame blocks, 750 blocks (one second
+    at 48 kHz) through the JACK process() callback of the host program, bit-exact vs the oracle."""
+    ev, out = tmp_path / "ev.bin", tmp_path / "out.f32"
+    _events_file(ev, [(0, [0x90, 69, 100])])
+    r = subprocess.run([SYNTH_ELF, "--fake-jack", "750", "64", str(ev), str(out)],
+                       stdin=subprocess.DEVNULL, capture_output=True, timeout=300)
+    assert r.returncode == 1, r.stderr.decode()
+    got = np.fromfile(out, np.float32)
+    n2v = np.zeros(128, np.int32)
+    inc = np.zeros(64, np.uint32)
+    st = np.zeros(64, np.uint32)
+    orc.orc_note_on(n2v, inc, 64, 69)
+    want = oracle.synth_run(orc, inc, st, 750 * 64)[1]
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the saw wraps 440 times per second: the phase after one second is 48000 * inc(69)
+    assert st[0] == (48000 * 39370533) & 0xFFFFFFFF
