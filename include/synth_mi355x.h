@@ -88,6 +88,10 @@ uint32_t  smx_bank_voices(const smx_bank *b);
  * Either pointer may be NULL to skip that array. */
 int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *state);
 int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state);
+/* smx_bank_load(inc, state) + smx_bank_run(vec, bus, n) with a single host
+ * synchronisation (what the drop-in synth_run does per block). */
+int smx_bank_load_run(smx_bank *b, const uint32_t *inc, const uint32_t *state, float *vec,
+                      int32_t *bus, int n);
 
 /* note_on/off over N voices with the reference's allocator semantics:
  * first free voice, steal voice 0 when full, phase not reset, note_off of a

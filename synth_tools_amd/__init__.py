@@ -83,6 +83,7 @@ ABI = [
     ("smx_bank_voices", C.c_uint32, [_P]),
     ("smx_bank_load", C.c_int, [_P, _P, _P]),
     ("smx_bank_read", C.c_int, [_P, _P, _P]),
+    ("smx_bank_load_run", C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     ("smx_bank_note_on", C.c_int, [_P, C.c_int]),
     ("smx_bank_note_off", C.c_int, [_P, C.c_int]),
     ("smx_bank_midi_event", C.c_int, [_P, _u8, C.c_size_t]),

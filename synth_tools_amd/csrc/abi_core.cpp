@@ -118,11 +118,14 @@ static void dropin_run(struct synth *x, float *vec, int n, bool square)
     }
     uint32_t inc[64], state[64];
     for (int v = 0; v < 64; v++) { inc[v] = x->voice[v].note_inc; state[v] = x->voice[v].note_state; }
-    SMX_ASSERT_OK(smx_bank_load(g_dropin, inc, state), "synth_run: load");
-    if (square) SMX_ASSERT_OK(smx_bank_run_square(g_dropin, vec, n), "sum_tick_square: run");
-    else        SMX_ASSERT_OK(smx_bank_run(g_dropin, vec, nullptr, n), "synth_run: run");
-    SMX_ASSERT_OK(smx_bank_read(g_dropin, nullptr, state), "synth_run: read");
-    for (int v = 0; v < 64; v++) x->voice[v].note_state = state[v];
+    if (square) {
+        SMX_ASSERT_OK(smx_bank_load(g_dropin, inc, state), "sum_tick_square: load");
+        SMX_ASSERT_OK(smx_bank_run_square(g_dropin, vec, n), "sum_tick_square: run");
+    } else {
+        SMX_ASSERT_OK(smx_bank_load_run(g_dropin, inc, state, vec, nullptr, n), "synth_run: run");
+    }
+    // the advanced phases in closed form (an off voice does not advance): no read-back needed
+    for (int v = 0; v < 64; v++) x->voice[v].note_state = state[v] + (uint32_t)n * inc[v];
 }
 
 extern "C" void synth_run(struct synth *x, float *vec, int n)

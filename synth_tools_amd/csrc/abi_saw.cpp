@@ -252,6 +252,21 @@ extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *s
     return SMX_OK;
 }
 
+// load + run + fetch with ONE host synchronisation (the drop-in synth_run uses it per block)
+extern "C" int smx_bank_load_run(smx_bank *b, const uint32_t *inc, const uint32_t *state, float *vec,
+                                 int32_t *bus, int n)
+{
+    if (!b || !inc || !state || n <= 0) { set_error("smx_bank_load_run: bad args"); return SMX_E_ARG; }
+    SMX_HIP(hipSetDevice(b->device));
+    // pageable sources: hipMemcpyAsync stages them before returning, so the caller's arrays may
+    // change right after the call; both copies and the kernel are ordered on the bank's stream
+    SMX_HIP(hipMemcpyAsync(b->d_inc, inc, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
+    SMX_HIP(hipMemcpyAsync(b->d_state0, state, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
+    b->elapsed = 0;
+    b->free_map.load(inc, b->n);
+    return smx_bank_run(b, vec, bus, n);
+}
+
 extern "C" int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state)
 {
     if (!b) { set_error("smx_bank_read: null bank"); return SMX_E_ARG; }
