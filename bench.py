@@ -353,7 +353,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "saw_bank_kernel", "kernel_ms": round(kernel_ms, 5),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "bytes_per_voice": 8,
+                         "note": "8 B read per voice per launch (inc + phase base); the advanced phase is kept as "
+                                 "state0 + elapsed*inc and never written back, so SURVEY 8d's 4-byte state write "
+                                 "(12 B/voice) does not exist on this path; PMC traffic agrees (profiles/)"},
         }
         if world == 1 and not a.no_cpu:
             single, par = cpu_baseline_saw(inc, state, a.frames, a.cpu_seconds)
