@@ -4,6 +4,10 @@ This is a thin test/bench driver over the C-ABI; the product is the shared
 library.  There is no Python or CPU implementation of any compute path here:
 if the HIP library is missing, import fails; if no GPU is visible, every
 compute call raises.
+
+Load order: a process that also uses PyTorch-ROCm must `import torch` BEFORE this package
+(as bench.py does).  The torch wheel bundles its own HIP runtime; loaded second, it leaves
+this library's runtime without a device ("no HIP device").
 """
 import ctypes as C
 import os

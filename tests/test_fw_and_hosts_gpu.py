@@ -167,3 +167,29 @@ def test_c1_one_voice_750_blocks(tmp_path, orc):
     assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
     # the saw wraps 440 times per second: the phase after one second is 48000 * inc(69)
     assert st[0] == (48000 * 39370533) & 0xFFFFFFFF
+
+
+def test_create_destroy_cycles_do_not_leak(smx):
+    """200 create/run/destroy cycles of every bank type leave device memory where it was."""
+    hip = C.CDLL("libamdhip64.so")            # the runtime the library already loaded
+
+    def free_bytes():
+        free, total = C.c_size_t(), C.c_size_t()
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    smx.SawBank(64).close()                   # make sure the device context exists
+    free0 = free_bytes()
+    nodes = [(smx.PROC_EDGE, smx.cproc_input(0), 1), (smx.PROC_ACC, 0, 1)]
+    for _ in range(200):
+        b = smx.SawBank(5000); b.run(64); b.close()
+        p = smx.PdmBank(3000); p.tick_n(70, want_bits=False); p.close()
+        w = smx.PwmBank(2000); w.tick_n(10, want_duty=False); w.close()
+        q = smx.PolyBank(1000); q.run(8); q.close()
+        o = smx.OscBank(500); o.tick_n(5, want_duty=False); o.close()
+        c = smx.ClockBank(100); c.run(5); c.close()
+        g = smx.CprocBank(300, nodes, 1); g.tick_n(np.zeros((2, 1, 300), np.uint32)); g.close()
+        f = smx.Firmware(3, 1); f.tick_n(5); f.close()
+    free1 = free_bytes()
+    assert free0 - free1 < 64 << 20, "device memory shrank by %d MiB" % ((free0 - free1) >> 20)
