@@ -10,6 +10,7 @@ struct smx_poly {
     int device = 0;
     smx::PolyArrays d{};               // device arrays
     int32_t *d_bus = nullptr;          // int32[2*64]
+    int32_t *d_slots = nullptr;        // bus copies the workgroups add into (poly_bank.hip), kept zero
     int32_t *h_bus = nullptr;          // pinned
     hipStream_t stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
@@ -43,6 +44,8 @@ extern "C" smx_poly *smx_poly_create(uint32_t n_voices, int device)
               hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&p->ev_t0) == hipSuccess && hipEventCreate(&p->ev_t1) == hipSuccess &&
               hipMalloc((void **)&p->d_bus, 128 * 4) == hipSuccess &&
+              hipMalloc((void **)&p->d_slots, smx::poly_scratch_bytes()) == hipSuccess &&
+              hipMemsetAsync(p->d_slots, 0, smx::poly_scratch_bytes(), p->stream) == hipSuccess &&
               hipHostMalloc((void **)&p->h_bus, 128 * 4, hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 12; i++)
         ok = hipMalloc(slots[i], bytes) == hipSuccess &&
@@ -66,6 +69,7 @@ extern "C" void smx_poly_destroy(smx_poly *p)
     for (int i = 0; i < 12; i++)
         if (*slots[i]) (void)hipFree(*slots[i]);
     if (p->d_bus) (void)hipFree(p->d_bus);
+    if (p->d_slots) (void)hipFree(p->d_slots);
     if (p->h_bus) (void)hipHostFree(p->h_bus);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
     if (p->ev_t1) (void)hipEventDestroy(p->ev_t1);
@@ -97,8 +101,7 @@ extern "C" int smx_poly_run_async(smx_poly *p, int n)
 {
     if (!p || n <= 0 || n > 64) { set_error("smx_poly_run_async: n=%d (1..64)", n); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(p->device));
-    SMX_HIP(hipMemsetAsync(p->d_bus, 0, (size_t)n * 8, p->stream));
-    return smx::launch_poly_bank(p->d, p->d_bus, p->n_pad, (uint32_t)n, p->stream);
+    return smx::launch_poly_bank(p->d, p->d_bus, p->d_slots, p->n_pad, (uint32_t)n, p->stream);
 }
 
 extern "C" int smx_poly_sync(smx_poly *p)

@@ -69,8 +69,11 @@ struct PolyArrays {
     float *y, *a;
     uint32_t *level, *stage, *gate, *ar, *dr, *sl, *rr, *pan;
 };
-int launch_poly_bank(const PolyArrays &p, int32_t *d_bus_lr, uint32_t n_pad, uint32_t nframes,
-                     hipStream_t stream);
+// d_slots: poly_scratch_bytes() of zeroed device memory (left zeroed again by every launch);
+// d_bus_lr[0 .. 2*nframes) is overwritten, not accumulated into.
+size_t poly_scratch_bytes();
+int launch_poly_bank(const PolyArrays &p, int32_t *d_bus_lr, int32_t *d_slots, uint32_t n_pad,
+                     uint32_t nframes, hipStream_t stream);
 
 // Noise-shaped PWM bank (pwm_bank.hip): device SoA arrays, n_pad entries each.
 struct PwmArrays {

@@ -93,3 +93,47 @@ def test_poly_envelope_stages_all_visited(smx, orc, inc_table):
 def test_c4_256k_voices(smx, orc, inc_table):
     """BASELINE config 4 size: 262 144 poly voices, one 64-frame block, full oracle check."""
     _run_case(smx, orc, 262144, 0x5EED0004, inc_table, [64, 64])
+
+
+def test_poly_envelope_corner_rates(smx, orc, inc_table):
+    """Envelope parameters drawn from the corners of the integer state machine: rate 0 in every
+    stage (holds, and "already at the target" arrivals), rates that overshoot in one frame,
+    sustain level 0 / MAX, levels sitting exactly on the arrival bounds, every stage as the
+    loaded state, gates flipping between blocks."""
+    n = 4096
+    rng = np.random.default_rng(0xAD5)
+    MAX = 0xFFFFFFFF
+    corner = np.array([0, 1, 2, 255, 256, 0x7FFFFFFF, 0x80000000, MAX - 256, MAX - 1, MAX], np.uint32)
+
+    def pick():
+        c = corner[rng.integers(0, len(corner), n)]
+        r = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        small = rng.integers(0, 1 << 20, n, dtype=np.uint64).astype(np.uint32)
+        which = rng.integers(0, 3, n)
+        return np.where(which == 0, c, np.where(which == 1, r, small)).astype(np.uint32)
+
+    arrs = synthetic.poly_bank(n, 0xAD5, inc_table, active_fraction=0.95)
+    arrs["ar"], arrs["dr"], arrs["sl"], arrs["rr"] = pick(), pick(), pick(), pick()
+    arrs["level"] = pick()
+    # a third of the levels exactly on / next to the arrival bounds sl + dr and rr
+    edge = rng.integers(0, 3, n) == 0
+    bound = (arrs["sl"].astype(np.uint64) + arrs["dr"] + rng.integers(0, 3, n).astype(np.uint64) - 1) & MAX
+    arrs["level"] = np.where(edge, bound.astype(np.uint32), arrs["level"])
+    arrs["stage"] = rng.integers(0, 5, n).astype(np.uint32)
+    arrs["gate"] = rng.integers(0, 2, n).astype(np.uint32)
+    bank = smx.PolyBank(n)
+    bank.load(**arrs)
+    ob, keep = _oracle_bank(arrs)
+    for nf in (1, 2, 64, 3, 64, 17, 64, 64):
+        flip = rng.random(n) < 0.3
+        keep["gate"][:] = np.where(flip, 1 - keep["gate"], keep["gate"])
+        bank.load(gate=keep["gate"])
+        bus, _ = bank.run(nf)
+        want = np.zeros(2 * nf, np.int32)
+        orc.orc_poly_run(C.byref(ob), want, nf)
+        assert np.array_equal(bus.reshape(-1), want), nf
+        got = bank.read()
+        assert np.array_equal(got["level"], keep["level"]), nf
+        assert np.array_equal(got["stage"], keep["stage"]), nf
+    assert _ulp_diff(got["y"], keep["y"]) <= ULP_TOL
+    bank.close()
