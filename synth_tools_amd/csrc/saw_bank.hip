@@ -54,7 +54,20 @@ __device__ __forceinline__ T stream_load(const T *p)
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
 }
-template <int TC, int VW, bool NT>
+// Partial sums of one 64-frame chunk.  Workgroups add into one of a few slots per chunk
+// (few adders per address); saw_bank_finalize_kernel sums the slots and clears them.
+constexpr int SAW_SLOTS = 64;       // slots per chunk (unused ones stay zero)
+struct SawPartial {
+    unsigned long long L[64];     // sum over voices of (u_v(t) & 15)
+    unsigned long long U0, I;     // sum u_v(t0), sum inc_v
+    uint32_t W[64];               // carries out of the phase add at frame t (t -> t+1)
+};
+
+// SLOT: instead of one atomic per frame per workgroup on the bus itself (same-address integer
+// atomics serialise at ~20 ns: 2048 workgroups ending together cost 40 us), the workgroup adds
+// its frame sums into one of SAW_SLOTS copies (SawPartial::W) and saw_direct_finalize_kernel
+// folds them.  Used for >= 2^20-voice banks from 5 frames up (launch_vw).
+template <int TC, int VW, bool NT, bool SLOT>
 __global__ __launch_bounds__(256)
 void saw_bank_kernel(const uint32_t *__restrict__ inc,
                      const uint32_t *__restrict__ st_in,   // state0[]
@@ -62,7 +75,8 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
                      int32_t *__restrict__ bus_next,   // zeroed here for the NEXT launch
                      uint32_t ngroups,      // n_pad / VW
                      uint32_t nframes,      // total frames of this block
-                     uint32_t tbase)        // frames elapsed since state0 was valid
+                     uint32_t tbase,        // frames elapsed since state0 was valid
+                     SawPartial *__restrict__ partial)   // SLOT only: zeroed slots, SAW_SLOTS per chunk
 {
     __shared__ int32_t M[TC][65];
     const uint32_t tid = threadIdx.x;
@@ -73,7 +87,7 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     for (uint32_t i = tid; i < TC * 65; i += 256) (&M[0][0])[i] = 0;
     // the bus is accumulated with atomics, so it must start at zero: each launch
     // clears the buffer its successor will use (saves a fill kernel per step)
-    if (blockIdx.x == 0 && blockIdx.y == 0)
+    if (!SLOT && blockIdx.x == 0 && blockIdx.y == 0)
         for (uint32_t i = tid; i < nframes; i += 256) bus_next[i] = 0;
 
     int32_t acc[TC];
@@ -140,7 +154,36 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
-    if (q == 0 && t < TC && f0 + t < nframes) atomicAdd(&bus[f0 + t], s);
+    if constexpr (SLOT) {
+        SawPartial *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
+        if (q == 0 && t < TC && f0 + t < nframes) atomicAdd(&out->W[t], (uint32_t)s);
+    } else {
+        if (q == 0 && t < TC && f0 + t < nframes) atomicAdd(&bus[f0 + t], s);
+    }
+}
+
+// Fold the slots of the direct formulation (one workgroup per 64-frame chunk), clear them for the
+// next launch, write the bus and keep the "next bus buffer is zero" contract.
+__global__ __launch_bounds__(256)
+void saw_direct_finalize_kernel(SawPartial *__restrict__ partial, int32_t *__restrict__ bus,
+                                int32_t *__restrict__ bus_next, uint32_t nframes)
+{
+    __shared__ uint32_t Ws[4][64];
+    const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
+    SawPartial *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
+    uint32_t wv[SAW_SLOTS / 4];
+#pragma unroll
+    for (int k = 0; k < SAW_SLOTS / 4; k++) wv[k] = p[part + 4 * k].W[t];
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < SAW_SLOTS / 4; k++) { w += wv[k]; p[part + 4 * k].W[t] = 0; }
+    Ws[part][t] = w;
+    __syncthreads();
+    const uint32_t f = blockIdx.x * 64u + t;
+    if (part == 0 && f < nframes) {
+        bus[f] = (int32_t)(Ws[0][t] + Ws[1][t] + Ws[2][t] + Ws[3][t]);
+        bus_next[f] = 0;
+    }
 }
 
 // Few-frame blocks (the tick ABI: 1..4 frames) of banks with >= 2^20 voices: the same direct
@@ -201,15 +244,6 @@ void saw_tick_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restric
 // ---------------------------------------------------------------------------
 // carry-count formulation (see the header comment)
 // ---------------------------------------------------------------------------
-// Partial sums of one 64-frame chunk.  Workgroups add into one of a few slots per chunk
-// (few adders per address); saw_bank_finalize_kernel sums the slots and clears them.
-constexpr int SAW_SLOTS = 64;       // slots per chunk (unused ones stay zero)
-struct SawPartial {
-    unsigned long long L[64];     // sum over voices of (u_v(t) & 15)
-    unsigned long long U0, I;     // sum u_v(t0), sum inc_v
-    uint32_t W[64];               // carries out of the phase add at frame t (t -> t+1)
-};
-
 // Four voices advance one frame: 4 x v_add_co_u32 (carry-outs as SGPR masks).  The
 // carries of voices 0/1 are counted per lane by v_addc_co_u32; those of voices 2/3
 // are returned as a scalar population count.  All SGPR masks are consumed >= 3
@@ -466,28 +500,45 @@ static uint32_t grid_size(uint32_t tc, uint32_t rows, uint32_t gy)
 
 template <int TC, int VW, bool NT>
 int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bus_next,
-              uint32_t n_pad, uint32_t nframes, uint32_t tbase, hipStream_t stream)
+              uint32_t n_pad, uint32_t nframes, uint32_t tbase, SawPartial *partial, hipStream_t stream)
 {
     const uint32_t ngroups = n_pad / VW;
     const uint32_t gy = (nframes + 63) / 64;
-    const uint32_t gx = grid_size(TC, (ngroups + 255) / 256, gy);
-    hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT>), dim3(gx, gy), dim3(256), 0, stream,
-                       inc, si, bus, bus_next, ngroups, nframes, tbase);
+    const uint32_t rows = (ngroups + 255) / 256;
+    if constexpr (VW == 4 && TC >= 8) {
+        static const bool no_slots = getenv("SMX_SAW_NO_SLOTS") != nullptr;     // A/B switch
+        if (partial && !no_slots) {
+            // slots: the bus atomics no longer bound the workgroup count -- one row per workgroup
+            // while the chip has room (8 workgroups per CU), grid-stride above that
+            static const char *env = getenv("SMX_SAW_SLOT_GRID");               // tuning override
+            uint32_t gx = ((env ? (uint32_t)atoi(env) : 2048u) + gy - 1) / gy;
+            if (gx > rows) gx = rows;
+            hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT, true>), dim3(gx, gy), dim3(256), 0, stream,
+                               inc, si, bus, bus_next, ngroups, nframes, tbase, partial);
+            hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3(gy), dim3(256), 0, stream, partial, bus,
+                               bus_next, nframes);
+            SMX_HIP(hipGetLastError());
+            return SMX_OK;
+        }
+    }
+    const uint32_t gx = grid_size(TC, rows, gy);
+    hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT, false>), dim3(gx, gy), dim3(256), 0, stream,
+                       inc, si, bus, bus_next, ngroups, nframes, tbase, (SawPartial *)nullptr);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
 
 template <int VW, bool NT>
 int launch_vw(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bus_next,
-              uint32_t n_pad, uint32_t nframes, uint32_t tbase, hipStream_t stream)
+              uint32_t n_pad, uint32_t nframes, uint32_t tbase, SawPartial *partial, hipStream_t stream)
 {
-    if (nframes > 32) return launch_tc<64, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
-    if (nframes > 16) return launch_tc<32, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
-    if (nframes > 8)  return launch_tc<16, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
-    if (nframes > 4)  return launch_tc<8, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
-    if (nframes > 2)  return launch_tc<4, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
-    if (nframes > 1)  return launch_tc<2, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
-    return launch_tc<1, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, stream);
+    if (nframes > 32) return launch_tc<64, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nframes > 16) return launch_tc<32, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nframes > 8)  return launch_tc<16, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nframes > 4)  return launch_tc<8, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nframes > 2)  return launch_tc<4, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nframes > 1)  return launch_tc<2, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    return launch_tc<1, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
 }
 
 }  // namespace
@@ -562,11 +613,15 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     // 4 voices per lane once there are enough voices to fill the chip that way;
     // non-temporal streaming once the bank (12 B/voice) cannot live in the 256 MiB
     // Infinity Cache between launches anyway
+    // slots need one SawPartial row per 64-frame chunk in the scratch
+    SawPartial *part = nullptr;
+    if (d_scratch && (size_t)SAW_SLOTS * ((nframes + 63) / 64) * sizeof(SawPartial) <= saw_scratch_bytes(nframes))
+        part = static_cast<SawPartial *>(d_scratch);
     if (n_pad >= (1u << 24))
-        return launch_vw<4, true>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, stream);
+        return launch_vw<4, true>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, stream);
     if (n_pad >= (1u << 20))
-        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, stream);
-    return launch_vw<1, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, stream);
+        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, stream);
+    return launch_vw<1, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, nullptr, stream);
 }
 
 int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in, uint32_t *d_or_bus,
