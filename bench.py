@@ -272,7 +272,10 @@ def main():
         sys.exit("bench.py: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # SMX_BENCH_FORCE_DIST: rehearse the N > 1 control path (torch process group + in-library RCCL
+    # communicator in one process) with a single rank under torch.distributed.run
+    force_dist = world == 1 and bool(os.environ.get("SMX_BENCH_FORCE_DIST")) and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -282,15 +285,15 @@ def main():
     bank = sta.SawBank(a.voices, device=local)
     bank.load(inc, state)
 
-    if world > 1:
+    if dist:
         uid = torch.zeros(sta.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid.copy_(torch.from_numpy(sta.comm_unique_id()))
         dist.broadcast(uid, 0)
         bank.comm_init(rank, world, uid.cpu().numpy())
 
-    comm = world > 1
-    if world == 1 and os.environ.get("SMX_BENCH_FORCE_COMM"):
+    comm = dist is not None
+    if not comm and os.environ.get("SMX_BENCH_FORCE_COMM"):
         # rehearsal of the multi-GPU code path on one GPU: 1-rank RCCL communicator
         bank.comm_init(0, 1, sta.comm_unique_id())
         comm = True
