@@ -84,13 +84,18 @@ static jack_port_t *midi_in, *audio_out; /* linux/synth.c:214-221 */
 static inline void process_midi(jack_nframes_t nframes) {        /* linux/synth.c:227-260 */
     void *midi_in_buf = jack.port_get_buffer(midi_in, nframes);
     jack_nframes_t n = jack.midi_get_event_count(midi_in_buf);
+    static uint8_t batch[3 * 4096];          /* bank mode: the block's 3-byte events, one call */
+    size_t nbatch = 0;
     for (jack_nframes_t i = 0; i < n; i++) {
         jack_midi_event_t event;
         jack.midi_event_get(&event, midi_in_buf, i);
         const uint8_t *msg = event.buffer;
-        if (bank) ASSERT(0 == smx_bank_midi_event(bank, msg, event.size));
-        else      synth_midi_event(&synth, msg, event.size);
+        if (!bank) { synth_midi_event(&synth, msg, event.size); continue; }
+        if (event.size != 3) continue;           /* linux/synth.c:236: only 3-byte events */
+        if (nbatch == 4096) { ASSERT(0 == smx_bank_midi_events(bank, batch, nbatch)); nbatch = 0; }
+        memcpy(batch + 3 * nbatch++, msg, 3);
     }
+    if (nbatch) ASSERT(0 == smx_bank_midi_events(bank, batch, nbatch));
 }
 static inline void process_audio(jack_nframes_t nframes) {       /* linux/synth.c:261-276 */
     jack_default_audio_sample_t *dst = jack.port_get_buffer(audio_out, nframes);

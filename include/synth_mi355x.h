@@ -101,6 +101,11 @@ int smx_bank_note_off(smx_bank *b, int note);
 /* MIDI dispatch of process_midi (linux/synth.c:236-258) for one event; the updates
  * are queued on the bank's stream ahead of the next block, without a host sync. */
 int smx_bank_midi_event(smx_bank *b, const uint8_t *msg, size_t size);
+/* The event loop of process_midi (linux/synth.c:246-258) for all events of a block at once:
+ * msgs3 holds n_events consecutive 3-byte messages (process_midi ignores every other size, so
+ * the caller leaves those out).  Same result as n_events calls of smx_bank_midi_event, applied
+ * by one copy and one kernel on the bank's stream. */
+int smx_bank_midi_events(smx_bank *b, const uint8_t *msgs3, size_t n_events);
 
 /* synth_run over the bank (linux/synth.c:196-202).  vec: host float[n] or
  * NULL; bus: host int32[n] or NULL (the integer sum before the 2^-32 scale,

@@ -91,6 +91,7 @@ ABI = [
     ("smx_bank_note_on", C.c_int, [_P, C.c_int]),
     ("smx_bank_note_off", C.c_int, [_P, C.c_int]),
     ("smx_bank_midi_event", C.c_int, [_P, _u8, C.c_size_t]),
+    ("smx_bank_midi_events", C.c_int, [_P, _u8, C.c_size_t]),
     ("smx_bank_run", C.c_int, [_P, _P, _P, C.c_int]),
     ("smx_bank_set_block_mode", C.c_int, [_P, C.c_int]),
     ("smx_bank_run_async", C.c_int, [_P, C.c_int]),
@@ -247,6 +248,11 @@ class SawBank:
     def midi_event(self, msg):
         m = np.ascontiguousarray(msg, np.uint8)
         _check(lib().smx_bank_midi_event(self._h, m, len(m)), "smx_bank_midi_event")
+
+    def midi_events(self, msgs):
+        """All 3-byte MIDI events of a block at once: msgs is (n, 3) uint8."""
+        m = np.ascontiguousarray(msgs, np.uint8).reshape(-1, 3)
+        _check(lib().smx_bank_midi_events(self._h, m.reshape(-1), len(m)), "smx_bank_midi_events")
 
     def run(self, n):
         """synth_run for n frames -> (bus int32[n], vec float32[n])."""

@@ -3,6 +3,7 @@
 // point needs a HIP device and fails with SMX_E_NOGPU otherwise.
 #include "abi_internal.h"
 #include <rccl/rccl.h>
+#include <unordered_map>
 
 namespace smx {
 
@@ -121,6 +122,15 @@ struct smx_bank {
     int rank = 0, nranks = 1;
     int note2voice[128];
     smx::FreeMap free_map;
+    // smx_bank_midi_events: (voice, increment) pairs of one batch, staged in pinned memory (two
+    // slots, so the host can fill one while the copy of the other is in flight) and a device copy
+    uint32_t *h_ev[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    bool ev_stage_busy[2] = {false, false};
+    uint32_t ev_cap = 0;                         // pairs per slot
+    uint32_t *d_ev = nullptr;
+    int ev_k = 0;
+    std::unordered_map<uint32_t, uint32_t> ev_net;   // voice -> index of its pair in the batch
 };
 
 static int bank_comm_flush(smx_bank *b);
@@ -216,6 +226,11 @@ extern "C" void smx_bank_destroy(smx_bank *b)
         if (b->ev_pipe[i]) (void)hipEventDestroy(b->ev_pipe[i]);
     }
     if (b->d_scratch) (void)hipFree(b->d_scratch);
+    for (int i = 0; i < 2; i++) {
+        if (b->h_ev[i]) (void)hipHostFree(b->h_ev[i]);
+        if (b->ev_stage[i]) (void)hipEventDestroy(b->ev_stage[i]);
+    }
+    if (b->d_ev) (void)hipFree(b->d_ev);
     if (b->ev_t0) (void)hipEventDestroy(b->ev_t0);
     if (b->ev_t1) (void)hipEventDestroy(b->ev_t1);
     if (b->comm_stream) (void)hipStreamDestroy(b->comm_stream);
@@ -432,6 +447,71 @@ extern "C" int smx_bank_midi_event(smx_bank *b, const uint8_t *msg, size_t size)
     if (msg[0] == 0x90) return msg[2] == 0 ? smx_bank_note_off(b, msg[1]) : smx_bank_note_on(b, msg[1]);
     if (msg[0] == 0x80) return smx_bank_note_off(b, msg[1]);
     return SMX_OK;                                          // CC 23..31 on 0xB0: accepted, no action
+}
+
+// process_midi's event loop (linux/synth.c:246-258) for a whole block's events: the allocator
+// runs on the host in event order, exactly as n_events calls of smx_bank_midi_event would, and
+// the increments that result reach the GPU as ONE copy + ONE kernel (a burst of 1000 note-ons
+// costs two queue entries instead of 1000 launches).
+extern "C" int smx_bank_midi_events(smx_bank *b, const uint8_t *msgs3, size_t n_events)
+{
+    if (!b || (n_events && !msgs3)) { set_error("smx_bank_midi_events: bad args"); return SMX_E_ARG; }
+    if (n_events == 0) return SMX_OK;
+    if (n_events > 0x7FFFFFFFu) { set_error("smx_bank_midi_events: n_events=%zu", n_events); return SMX_E_RANGE; }
+    SMX_HIP(hipSetDevice(b->device));
+    if (b->ev_cap < n_events) {                              // grow the staging (never in steady state)
+        SMX_HIP(hipStreamSynchronize(b->stream));
+        uint32_t cap = b->ev_cap ? b->ev_cap : 1024u;
+        while (cap < n_events) cap *= 2;
+        for (int i = 0; i < 2; i++) {
+            if (b->h_ev[i]) SMX_HIP(hipHostFree(b->h_ev[i]));
+            b->h_ev[i] = nullptr;
+            SMX_HIP(hipHostMalloc((void **)&b->h_ev[i], (size_t)cap * 8, hipHostMallocDefault));
+            if (!b->ev_stage[i]) SMX_HIP(hipEventCreateWithFlags(&b->ev_stage[i], hipEventDisableTiming));
+            b->ev_stage_busy[i] = false;
+        }
+        if (b->d_ev) SMX_HIP(hipFree(b->d_ev));
+        b->d_ev = nullptr;
+        SMX_HIP(hipMalloc((void **)&b->d_ev, (size_t)cap * 8));
+        b->ev_cap = cap;
+        b->ev_net.reserve(cap);
+    }
+    const int k = b->ev_k;
+    if (b->ev_stage_busy[k]) {                               // the copy that last read this slot
+        SMX_HIP(hipEventSynchronize(b->ev_stage[k]));
+        b->ev_stage_busy[k] = false;
+    }
+    uint32_t *pairs = b->h_ev[k];
+    uint32_t npairs = 0;
+    b->ev_net.clear();
+    auto put = [&](uint32_t v, uint32_t inc) {
+        auto it = b->ev_net.find(v);
+        if (it == b->ev_net.end()) { b->ev_net.emplace(v, npairs); pairs[2 * npairs] = v; pairs[2 * npairs + 1] = inc; npairs++; }
+        else pairs[2 * it->second + 1] = inc;
+        b->free_map.set_free(v, inc == 0);
+    };
+    for (size_t i = 0; i < n_events; i++) {
+        const uint8_t *m = msgs3 + 3 * i;
+        const bool on = m[0] == 0x90 && m[2] != 0;
+        const bool off = (m[0] == 0x90 && m[2] == 0) || m[0] == 0x80;
+        const int note = m[1] % 128;
+        if (on) {                                            // linux/synth.c:156-160
+            int64_t v = b->free_map.first_free();
+            if (v < 0) v = 0;                                // steal voice 0 (:150-153)
+            b->note2voice[note] = (int)v;
+            put((uint32_t)v, note_to_inc(note));
+        } else if (off) {                                    // linux/synth.c:161-165
+            const int v = b->note2voice[note];
+            b->note2voice[note] = 0;
+            put((uint32_t)v, 0);
+        }
+    }
+    if (npairs == 0) return SMX_OK;
+    SMX_HIP(hipMemcpyAsync(b->d_ev, pairs, (size_t)npairs * 8, hipMemcpyHostToDevice, b->stream));
+    SMX_HIP(hipEventRecord(b->ev_stage[k], b->stream));
+    b->ev_stage_busy[k] = true;
+    b->ev_k ^= 1;
+    return smx::launch_saw_rebase_batch(b->d_inc, b->d_state0, b->d_ev, npairs, b->elapsed, b->stream);
 }
 
 extern "C" int smx_bank_sync(smx_bank *b)

@@ -470,6 +470,21 @@ __global__ void saw_rebase_kernel(uint32_t *__restrict__ inc, uint32_t *__restri
         inc[voice] = new_inc;
     }
 }
+// A block's worth of note events at once: pairs[2k] = voice, pairs[2k+1] = its increment after the
+// last event that touched it (the host applies the events to its allocator in order and keeps one
+// pair per voice: rebasing is linear in inc and all events of a batch share T, so only the final
+// increment matters).  Voices are distinct, one lane per pair.
+__global__ __launch_bounds__(256)
+void saw_rebase_batch_kernel(uint32_t *__restrict__ inc, uint32_t *__restrict__ state0,
+                             const uint32_t *__restrict__ pairs, uint32_t npairs, uint32_t tbase)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= npairs) return;
+    const uint32_t voice = pairs[2 * k], new_inc = pairs[2 * k + 1];
+    const uint32_t old = inc[voice];
+    state0[voice] += tbase * (old - new_inc);
+    inc[voice] = new_inc;
+}
 // Materialise every phase: state0 += T*inc (the host then resets T to 0).
 __global__ __launch_bounds__(256)
 void saw_materialize_kernel(const uint32_t *__restrict__ inc, uint32_t *__restrict__ state0,
@@ -642,6 +657,16 @@ int launch_saw_rebase(uint32_t *d_inc, uint32_t *d_state0, uint32_t voice, uint3
                       uint32_t tbase, hipStream_t stream)
 {
     hipLaunchKernelGGL(saw_rebase_kernel, dim3(1), dim3(64), 0, stream, d_inc, d_state0, voice, new_inc, tbase);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_saw_rebase_batch(uint32_t *d_inc, uint32_t *d_state0, const uint32_t *d_pairs, uint32_t npairs,
+                            uint32_t tbase, hipStream_t stream)
+{
+    if (npairs == 0) return SMX_OK;
+    hipLaunchKernelGGL(saw_rebase_batch_kernel, dim3((npairs + 255) / 256), dim3(256), 0, stream, d_inc,
+                       d_state0, d_pairs, npairs, tbase);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

@@ -52,6 +52,9 @@ int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state0, uint32_t
 // one voice's increment changes at elapsed time tbase; state0 += tbase*inc for all voices
 int launch_saw_rebase(uint32_t *d_inc, uint32_t *d_state0, uint32_t voice, uint32_t new_inc,
                       uint32_t tbase, hipStream_t stream);
+// npairs (voice, final increment) pairs with distinct voices, in device memory
+int launch_saw_rebase_batch(uint32_t *d_inc, uint32_t *d_state0, const uint32_t *d_pairs, uint32_t npairs,
+                            uint32_t tbase, hipStream_t stream);
 int launch_saw_materialize(const uint32_t *d_inc, uint32_t *d_state0, uint32_t n_pad, uint32_t tbase,
                            hipStream_t stream);
 // Carry-out PDM bank (pdm_bank.hip).  n_pad multiple of 1024; d_bits rows are n_pad/8 bytes.

@@ -231,6 +231,39 @@ def test_midi_event_bursts_without_sync(smx, orc):
     bank.close()
 
 
+def test_midi_events_batched_equals_event_by_event(smx, orc):
+    """smx_bank_midi_events (one copy + one kernel per block) against the oracle's event-by-event
+    allocator: bursts larger than the bank (voice 0 stolen over and over), the same voice touched
+    many times in one batch, stray note-offs, ignored status bytes, batches growing past the
+    initial staging capacity, batched and single-event calls interleaved, and blocks in between
+    so that the rebase happens at a non-zero elapsed time."""
+    n = 2500
+    bank = smx.SawBank(n)
+    n2v = np.zeros(128, np.int32)
+    inc = np.zeros(n, np.uint32)
+    st = np.zeros(n, np.uint32)
+    rng = np.random.default_rng(77)
+    for burst in (3, 900, 7000, 1, 0, 2000):
+        status = rng.choice(np.array([0x90, 0x90, 0x90, 0x80, 0xB0], np.uint8), burst)
+        notes = rng.integers(0, 200, burst).astype(np.uint8)          # > 127 exercises note % 128
+        vel = (rng.integers(0, 3, burst) * 50).astype(np.uint8)
+        msgs = np.stack([status, notes, vel], axis=1) if burst else np.zeros((0, 3), np.uint8)
+        bank.midi_events(msgs)
+        for m in msgs:
+            orc.orc_midi_event(n2v, inc, n, np.ascontiguousarray(m), 3)
+        # one more event through the single-event entry, behind the batch
+        m = np.array([0x90, int(rng.integers(0, 128)), 100], np.uint8)
+        bank.midi_event(m)
+        orc.orc_midi_event(n2v, inc, n, m, 3)
+        nf = int(rng.integers(1, 100))
+        bus, _ = bank.run(nf)
+        obus, _ = oracle.synth_run(orc, inc, st, nf)
+        assert np.array_equal(bus, obus), burst
+    ginc, gst = bank.read()
+    assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+    bank.close()
+
+
 def test_long_blocks_grow_the_bus(smx, orc, inc_table):
     """Blocks longer than the initial 4096-frame bus capacity: the bus buffers (and, for a
     big bank, the carry formulation's scratch slots) are reallocated between blocks."""
