@@ -367,3 +367,43 @@ def test_tick_kernel_1_to_4_frames(smx, orc, inc_table):
     n = 1 << 21
     inc, state = synthetic.saw_bank(n, 0x5EED0A11, inc_table, active_fraction=0.85)
     _check(smx, orc, inc, state, [1, 2, 3, 4, 1, 1, 64, 3])
+
+
+def test_billion_voice_bank_index_safety(smx):
+    """2^30 + 3072 voices (8 GiB of bank state; every byte offset beyond 2^32): the 1-frame tick
+    path, a 16-frame block (direct formulation with bus slots) and a 64-frame block (carry
+    formulation) against the closed form  bus[t] = sum_v ((int32)(state_v + t*inc_v) >> 4)
+    evaluated with numpy for frames 0, 1, 15 and 63, then the phases read back.  Voice values depend
+    on the index, so a workgroup reading the wrong rows (32-bit index wrap) changes the sums."""
+    n = (1 << 30) + 3072
+    idx = np.arange(n, dtype=np.uint64)
+    inc = ((idx * np.uint64(2654435761)) >> np.uint64(7)).astype(np.uint32) | np.uint32(1)
+    state = ((idx * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(29)).astype(np.uint32)
+    inc[5::1000003] = 0                                   # a few voices off
+    del idx
+
+    def closed_form(t):
+        ph = state + np.uint32(t) * inc
+        ph[inc == 0] = 0                                  # off voices contribute nothing
+        return np.int64((ph.view(np.int32) >> 4).sum(dtype=np.int64))
+
+    def wrap(x):
+        return np.int32(np.uint32(x & 0xFFFFFFFF))
+
+    bank = smx.SawBank(n)
+    bank.load(inc, state)
+    f0, f1, f15, f63 = (closed_form(t) for t in (0, 1, 15, 63))
+    # off voices are parked at phase 0 and do not advance: their closed-form term is 0 at every t
+    bus, _ = bank.run(1)
+    assert bus[0] == wrap(f0)
+    bank.load(inc, state)
+    bus, _ = bank.run(16)
+    assert bus[0] == wrap(f0) and bus[1] == wrap(f1) and bus[15] == wrap(f15)
+    bank.load(inc, state)
+    bus, _ = bank.run(64)
+    assert bus[0] == wrap(f0) and bus[1] == wrap(f1) and bus[15] == wrap(f15) and bus[63] == wrap(f63)
+    ginc, gst = bank.read()
+    assert np.array_equal(ginc, inc)
+    want = state + np.uint32(64) * inc                    # inc == 0: unchanged
+    assert np.array_equal(gst, want)
+    bank.close()
