@@ -139,3 +139,38 @@ def test_channel_stream_layout(smx, orc, n, with_dither):
     with pytest.raises(smx.SmxError):
         bank.tick_n_streams(33)
     bank.close()
+
+
+def test_quarter_billion_channels_index_safety(smx):
+    """2^28 + 1000 channels (the tick-major pulse matrix of 100 ticks is 3.4 GB: offsets beyond
+    2^32), dither 0, against closed forms that need no per-tick loop:
+      accu after T ticks        = accu0 + T*setpoint                      (mod 2^32)
+      pulses of channel c so far = floor((accu0_c + T*setpoint_c) / 2^32)
+    so the popcount of tick rows 0..T-1 must equal the sum of those floors (checked at T = 1, 64 and
+    100: a full tile, a ragged tile and one tick), and channel c's own pulses of the first 64
+    ticks must be its carry sequence (checked on scattered channels incl. the last one)."""
+    n = (1 << 28) + 1000
+    idx = np.arange(n, dtype=np.uint64)
+    sp = (np.uint64(0x40000000) + ((idx * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(33))).astype(np.uint32)
+    a0 = ((idx * np.uint64(2654435761)) >> np.uint64(3)).astype(np.uint32)
+    del idx
+    bank = smx.PdmBank(n)
+    bank.load(sp, a0)
+    T = 100
+    bits = bank.tick_n(T)                                      # (T, words) uint32
+    assert bits.shape == (T, (n + 31) // 32)
+    row_counts = np.bitwise_count(bits).sum(axis=1, dtype=np.int64)
+    for t_end in (1, 64, 100):
+        want = np.int64(((a0.astype(np.uint64) + np.uint64(t_end) * sp) >> np.uint64(32)).sum(dtype=np.uint64))
+        assert row_counts[:t_end].sum() == want, t_end
+    for c in (0, 1, 63, 64, 1023, 1024, (1 << 24) + 5, (1 << 28) - 1, 1 << 28, n - 1):
+        acc = np.uint64(a0[c])
+        for t in range(64):
+            nxt = acc + np.uint64(sp[c])
+            pulse = int(nxt >> np.uint64(32))
+            acc = nxt & np.uint64(0xFFFFFFFF)
+            assert (int(bits[t, c >> 5]) >> (c & 31)) & 1 == pulse, (c, t)
+    gsp, gac = bank.read()
+    assert np.array_equal(gsp, sp)
+    assert np.array_equal(gac, a0 + np.uint32(T) * sp)
+    bank.close()
