@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libsynth_mi355x.so")
 SOURCES = ["saw_bank.hip", "pdm_bank.hip", "poly_bank.hip", "pwm_bank.hip", "osc_bank.hip", "cproc_bank.hip",
            "abi_core.cpp", "abi_saw.cpp", "abi_pdm.cpp", "abi_pwm.cpp", "abi_poly.cpp", "abi_osc.cpp",
            "abi_cproc.cpp", "abi_fw.cpp"]
-HEADERS = ["smx_common.h", "abi_internal.h", os.path.join("..", "..", "include", "synth_mi355x.h")]
+HEADERS = ["smx_common.h", "abi_internal.h", "exports.map", os.path.join("..", "..", "include", "synth_mi355x.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-result"]
 
@@ -41,7 +41,8 @@ def build(force=False, verbose=False):
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (s, out.decode()))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + \
-          ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+          ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
     subprocess.check_call(cmd)
     return LIB
 

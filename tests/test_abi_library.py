@@ -32,6 +32,16 @@ def test_every_declared_symbol_is_exported():
     assert funcs | data == bound, "binding table and header disagree: %s" % sorted((funcs | data) ^ bound)
 
 
+def test_nothing_but_the_declared_abi_is_exported():
+    """The dynamic symbol table is the header, no more (csrc/exports.map): the C++ launchers
+    between the ABI files and the kernels are not part of the boundary."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", sta.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TBDRW"}
+    funcs, data = _declared_symbols()
+    assert exported == funcs | data, sorted(exported ^ (funcs | data))
+
+
 def test_note_tables_match_oracle(orc):
     L = sta.lib()
     for n in range(-3, 260):
