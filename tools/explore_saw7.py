@@ -1,0 +1,18 @@
+"""Scratch: carry formulation, 64 Mi voices x 32/64/1024 frames (run with SMX_SAW_CARRY_GRID=...)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import synth_tools_amd as sta
+from synth_tools_amd import synthetic
+tab = synthetic.note_inc_table(sta.lib().note_to_inc)
+n = 1 << 26
+inc, st = synthetic.saw_bank(n, 1, tab)
+b = sta.SawBank(n); b.load(inc, st)
+line = "grid=%s" % os.environ.get("SMX_SAW_CARRY_GRID", "default")
+for B in (32, 64, 1024):
+    for _ in range(3): b.run_async(B)
+    b.sync(); K = 20 if B < 1024 else 4; b.timer_start()
+    for _ in range(K): b.run_async(B)
+    ms = b.timer_stop() / K
+    line += "  B=%d %8.1f us %7.0f Gs/s" % (B, ms * 1e3, n * B / ms / 1e6)
+print(line, flush=True)
+b.close()
