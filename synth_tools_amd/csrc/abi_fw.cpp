@@ -44,7 +44,7 @@ extern "C" uint32_t smx_fw_parameter(const smx_fw *f, uint32_t id) { return (f &
 extern "C" int smx_fw_handle_tag_u32(smx_fw *f, const uint32_t *args, uint32_t nb_args,
                                      const uint8_t *bytes, uint32_t nb_bytes)
 {
-    if (!f) return -1;
+    if (!f || (nb_args && !args) || (nb_bytes && !bytes)) return -1;
     if (nb_args < 1) return -1;                              // mod_synth.c:91
     switch (args[0]) {
     case 100:                                                // MODE, :97-103

@@ -18,25 +18,39 @@
 
 namespace {
 
+// MAXN: compile-time bound of the node loop (4, 8, 16 or 32).  With the loop fully unrolled every
+// prog.nodes[k] is a loop-invariant kernel-argument load that the compiler hoists out of the tick
+// loop into scalar registers, and the node's own state address is an immediate LDS offset (the
+// run-time node loop re-read the table from the kernel arguments for every node of every tick).
+template <int MAXN>
 __global__ __launch_bounds__(256)
 void cproc_kernel(smx::CprocProgram prog, uint32_t *__restrict__ state,   // [node][2][n_pad]
                   const uint32_t *__restrict__ input,                      // [t][n_inputs][n_pad]
                   const uint32_t *__restrict__ g, uint32_t *__restrict__ out,  // [t][n_pad]
-                  uint32_t n_pad, uint32_t nticks, uint32_t out_node)
+                  uint32_t n_pad, uint32_t nticks, uint32_t out_node,
+                  uint32_t depth)                     // ticks of input staged ahead in LDS (0: none)
 {
-    extern __shared__ uint32_t lds[];                 // [n_nodes][2][256]
+    extern __shared__ uint32_t lds[];                 // [n_nodes][2][256], then [depth][n_inputs][256]
     const uint32_t tid = threadIdx.x, inst = blockIdx.x * 256u + tid;
     for (uint32_t k = 0; k < prog.n_nodes; k++) {
         lds[(k * 2 + 0) * 256 + tid] = state[((size_t)k * 2 + 0) * n_pad + inst];
         lds[(k * 2 + 1) * 256 + tid] = state[((size_t)k * 2 + 1) * n_pad + inst];
     }
-    for (uint32_t t = 0; t < nticks; t++) {
+    // The inputs do not depend on the state, so the rows of the next `depth` ticks are requested
+    // together (8 loads in flight per lane) and parked in the lane's own LDS column; a load inside
+    // the tick recurrence costs its full latency every tick (1 Mi instances x 256 ticks of the
+    // bp5 chain: 797 us with the load in the loop).
+    uint32_t *inbuf = lds + prog.n_nodes * 2 * 256 + tid;
+    const size_t in_stride = (size_t)prog.n_inputs * n_pad;
+    auto run_tick = [&](uint32_t t, const uint32_t *row, size_t word_stride) {
         const uint32_t gt = g ? g[t] : 0xFFFFFFFFu;
-        for (uint32_t k = 0; k < prog.n_nodes; k++) {           // allocation order
+#pragma unroll
+        for (int k = 0; k < MAXN; k++) {                        // allocation order
+            if ((uint32_t)k >= prog.n_nodes) break;
             const smx::CprocNode nd = prog.nodes[k];
             if (!(gt & nd.cond)) continue;                      // PROC_COND
             const uint32_t in = (nd.in & 0x80000000u)
-                ? input[((size_t)t * prog.n_inputs + (nd.in & 0x7FFFFFFFu)) * n_pad + inst]
+                ? row[(size_t)(nd.in & 0x7FFFFFFFu) * word_stride]
                 : lds[(nd.in * 2) * 256 + tid];
             uint32_t *o = &lds[(k * 2 + 0) * 256 + tid];
             uint32_t *l = &lds[(k * 2 + 1) * 256 + tid];
@@ -48,6 +62,24 @@ void cproc_kernel(smx::CprocProgram prog, uint32_t *__restrict__ state,   // [no
             }
         }
         if (out) out[(size_t)t * n_pad + inst] = lds[(out_node * 2) * 256 + tid];
+    };
+    if (depth == 0) {
+        for (uint32_t t = 0; t < nticks; t++) run_tick(t, input + (size_t)t * in_stride + inst, n_pad);
+    } else {
+        for (uint32_t t0 = 0; t0 < nticks; t0 += depth) {
+            const uint32_t nd_ticks = min(depth, nticks - t0);
+            const uint32_t rows = nd_ticks * prog.n_inputs;     // [t][word] is contiguous in rows
+            const uint32_t *base = input + (size_t)t0 * in_stride + inst;
+            for (uint32_t e0 = 0; e0 < rows; e0 += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = (e0 + i < rows) ? base[(size_t)(e0 + i) * n_pad] : 0u;
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (e0 + i < rows) inbuf[(e0 + i) * 256] = v[i];
+            }
+            for (uint32_t d = 0; d < nd_ticks; d++) run_tick(t0 + d, inbuf + d * prog.n_inputs * 256, 256);
+        }
     }
     for (uint32_t k = 0; k < prog.n_nodes; k++) {
         state[((size_t)k * 2 + 0) * n_pad + inst] = lds[(k * 2 + 0) * 256 + tid];
@@ -69,8 +101,19 @@ int launch_cproc(const CprocProgram &prog, uint32_t *d_state, const uint32_t *d_
         return SMX_E_ARG;
     }
     if (nticks == 0) return SMX_OK;
-    hipLaunchKernelGGL(cproc_kernel, dim3(n_pad / 256), dim3(256), prog.n_nodes * 2 * 256 * 4, stream,
-                       prog, d_state, d_input, d_g, d_out, n_pad, nticks, out_node);
+    // LDS: 2 KB of state per node; what is left of 64 KB stages up to 8 ticks of input (1 KB per word)
+    const uint32_t state_kb = prog.n_nodes * 2;
+    uint32_t depth = prog.n_inputs ? (64u - state_kb) / prog.n_inputs : 0u;
+    if (depth > 8) depth = 8;
+    const uint32_t lds_bytes = (state_kb + depth * prog.n_inputs) * 1024u;
+#define SMX_CPROC_LAUNCH(MAXN_)                                                                        \
+    hipLaunchKernelGGL(cproc_kernel<MAXN_>, dim3(n_pad / 256), dim3(256), lds_bytes,                   \
+                       stream, prog, d_state, d_input, d_g, d_out, n_pad, nticks, out_node, depth)
+    if (prog.n_nodes <= 4)       SMX_CPROC_LAUNCH(4);
+    else if (prog.n_nodes <= 8)  SMX_CPROC_LAUNCH(8);
+    else if (prog.n_nodes <= 16) SMX_CPROC_LAUNCH(16);
+    else                         SMX_CPROC_LAUNCH(32);
+#undef SMX_CPROC_LAUNCH
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

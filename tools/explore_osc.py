@@ -26,4 +26,11 @@ c.load(hperiod=(1000 + (r & np.uint64(0xFFFF))).astype(np.uint32))
 for _ in range(3):
     c.run(1024)
 c.close()
+from synth_tools_amd import PROC_ACC, PROC_EDGE, cproc_input
+nodes = [(PROC_EDGE, cproc_input(0), 1), (PROC_ACC, 0, 1), (PROC_ACC, 1, 1)]      # stm32f103/bp5_plugin.c:4-9
+cb = sta.CprocBank(n, nodes, 1)
+inp = (synthetic.splitmix64(21, 256 * n) & np.uint64(3)).astype(np.uint32).reshape(256, 1, n)
+for _ in range(3):
+    cb.tick_n(inp)
+cb.close()
 print("done", flush=True)
