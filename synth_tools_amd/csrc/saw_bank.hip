@@ -97,12 +97,21 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     // VW == 4: ngroups is a multiple of 256 (n_pad of 1024), so the grid-stride loop runs over
     // whole workgroup rows with a wave-uniform trip count, and the next row's 32 bytes per lane
     // are requested before the arithmetic on the current row (software prefetch).
+    // From 8 frames up (SLOT variants) the prefetch runs TWO rows ahead: one row of arithmetic
+    // (160..640 cycles x 8 waves per SIMD) is shorter than the HBM latency, and with one row in
+    // flight per wave the chip holds 16 MB in flight, ~5 TB/s at most.
+    constexpr bool PF2 = SLOT;
     const uint32_t nrows = ngroups >> 8;
-    u32x4 a_next = 0, b_next = 0;
+    u32x4 a_next = 0, b_next = 0, a_next2 = 0, b_next2 = 0;
     if constexpr (VW == 4) {
         if (blockIdx.x < nrows) {
             a_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + blockIdx.x * 256u + tid);
             b_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + blockIdx.x * 256u + tid);
+            if constexpr (PF2) {
+                const uint32_t r2 = min(blockIdx.x + gridDim.x, nrows - 1) * 256u + tid;
+                a_next2 = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + r2);
+                b_next2 = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + r2);
+            }
         }
     }
     const uint32_t g_first = (VW == 4) ? blockIdx.x : blockIdx.x * 256u + tid;
@@ -113,9 +122,16 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
         uint32_t vi[VW], vs[VW];
         if constexpr (VW == 4) {
             const u32x4 a = a_next, b = b_next;
-            const uint32_t rn = min(gi + gridDim.x, nrows - 1) * 256u + tid;   // last trip re-reads its row
-            a_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + rn);
-            b_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + rn);
+            if constexpr (PF2) {
+                a_next = a_next2; b_next = b_next2;
+                const uint32_t rn = min(gi + 2 * gridDim.x, nrows - 1) * 256u + tid;   // last trips re-read a row
+                a_next2 = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + rn);
+                b_next2 = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + rn);
+            } else {
+                const uint32_t rn = min(gi + gridDim.x, nrows - 1) * 256u + tid;       // last trip re-reads its row
+                a_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + rn);
+                b_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + rn);
+            }
             vi[0] = a.x; vi[1] = a.y; vi[2] = a.z; vi[3] = a.w;
             vs[0] = b.x; vs[1] = b.y; vs[2] = b.z; vs[3] = b.w;
         } else {
@@ -526,7 +542,9 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
             // slots: the bus atomics no longer bound the workgroup count -- one row per workgroup
             // while the chip has room (8 workgroups per CU), grid-stride above that
             static const char *env = getenv("SMX_SAW_SLOT_GRID");               // tuning override
-            uint32_t gx = ((env ? (uint32_t)atoi(env) : 2048u) + gy - 1) / gy;
+            // (5..8 frames are still a read stream first: 1024 workgroups, as in tick mode --
+            // 64 Mi voices x 5 frames 79 us = 6.8 TB/s vs 90 us with 2048)
+            uint32_t gx = ((env ? (uint32_t)atoi(env) : (TC <= 8 ? 1024u : 2048u)) + gy - 1) / gy;
             if (gx > rows) gx = rows;
             hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT, true>), dim3(gx, gy), dim3(256), 0, stream,
                                inc, si, bus, bus_next, ngroups, nframes, tbase, partial);
