@@ -131,12 +131,20 @@ def cpu_baselines_extra(synthetic, tab, budget_s=2.0):
     return out
 
 
-def time_saw(sta, bank, frames, steps, warmup, comm=False):
+def time_saw(sta, bank, frames, steps, warmup, comm=False, settle_ms=10.0):
+    """Average ms per step over `steps` steps.  The secondary workloads follow read-backs and CPU
+    work that leave the GPU idle, and the first milliseconds after an idle gap run up to 15 % slow
+    (clock ramp): besides the `warmup` steps, untimed steps are run until `settle_ms` have passed."""
+    t0 = time.perf_counter()
     for _ in range(warmup):
         bank.run_async(frames)
         if comm:
             bank.allreduce_async(frames)
     bank.sync()
+    while (time.perf_counter() - t0) * 1e3 < settle_ms:
+        for _ in range(max(1, warmup)):
+            bank.run_async(frames)
+        bank.sync()
     bank.timer_start()
     for _ in range(steps):
         bank.run_async(frames)
@@ -145,6 +153,16 @@ def time_saw(sta, bank, frames, steps, warmup, comm=False):
     ms = bank.timer_stop()
     bank.sync()
     return ms / steps
+
+
+def settle(step, sync, ms=10.0):
+    """Untimed steps until `ms` have passed (see time_saw): clock ramp after an idle gap."""
+    t0 = time.perf_counter()
+    while True:
+        step()
+        sync()
+        if (time.perf_counter() - t0) * 1e3 >= ms:
+            return
 
 
 def also_workloads(sta, synthetic, tab, big_bank, voices):
@@ -187,10 +205,9 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
         if with_d:
             # seeded dither for the perf leg only: parity tests cover explicit dither arrays
             p.tick_n(64, synthetic.dither_stream(64, 7, 0x0FFFFFFF), want_bits=False)
-        p.tick_n_async(nt, with_d)
-        p.sync()
+        settle(lambda: p.tick_n_async(nt, with_d), p.sync)
         p.timer_start()
-        reps = 5
+        reps = 20
         for _ in range(reps):
             p.tick_n_async(nt, with_d)
         ms = p.timer_stop() / reps
@@ -201,12 +218,11 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
                     "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     # the same bank with channel-stream output (no transpose: 2 instead of 3 vector ops per tick)
     for with_d in (False, True):
-        p.tick_n_streams_async(nt, with_d)
-        p.sync()
+        settle(lambda: p.tick_n_streams_async(nt, with_d), p.sync)
         p.timer_start()
-        for _ in range(5):
+        for _ in range(20):
             p.tick_n_streams_async(nt, with_d)
-        ms = p.timer_stop() / 5
+        ms = p.timer_stop() / 20
         alg = 12.0 * n + nt * n / 8.0
         out.append({"workload": "c3: carry-out PDM bank, %d channels, %d ticks/launch, channel-stream layout, dither=%s" % (n, nt, "seeded" if with_d else "0"),
                     "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
@@ -218,12 +234,11 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
     w = sta.PwmBank(n, order=2)
     w.load(setpoint=synthetic.pdm_bank(n, 0x5EED0008)[0])
     w.tick_n(8, synthetic.dither_stream(8, 7, 0x3FF), want_duty=False)
-    w.tick_n_async(nt, True)
-    w.sync()
+    settle(lambda: w.tick_n_async(nt, True), w.sync)
     w.timer_start()
-    for _ in range(5):
+    for _ in range(20):
         w.tick_n_async(nt, True)
-    ms = w.timer_stop() / 5
+    ms = w.timer_stop() / 20
     w.close()
     alg = 52.0 * n + float(nt) * n
     out.append({"workload": "noise-shaped PWM bank (pdm2+glide), %d channels, %d ticks/launch, dither seeded" % (n, nt),
@@ -234,11 +249,9 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
     n = 1 << 18
     pb = sta.PolyBank(n)
     pb.load(**synthetic.poly_bank(n, 0x5EED0004, tab))
-    for _ in range(3):
-        pb.run_async(64)
-    pb.sync()
+    settle(lambda: pb.run_async(64), pb.sync)
     pb.timer_start()
-    reps = 50
+    reps = 200
     for _ in range(reps):
         pb.run_async(64)
     ms = pb.timer_stop() / reps

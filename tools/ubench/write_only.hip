@@ -78,7 +78,7 @@ __global__ __launch_bounds__(BS) void w_wavechunk(u32x4 *out, size_t nvec)
 
 template <typename F> float timeit(F f, int reps) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) f();
+    for (int i = 0; i < 3 * reps; i++) f();          // sustained rate: short bursts are partly absorbed by the Infinity Cache
     (void)hipDeviceSynchronize(); (void)hipEventRecord(e0);
     for (int i = 0; i < reps; i++) f();
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
@@ -89,27 +89,27 @@ int main() {
     const uint32_t n = 1u << 20, nticks = 1024, n4 = n / 4;
     const size_t bytes = (size_t)n * nticks;
     uint32_t *out; (void)hipMalloc(&out, bytes);
-    float a = timeit([&] { hipLaunchKernelGGL((w_row4<false>), dim3(n4 / 256), dim3(256), 0, 0, out, n4, nticks); }, 10);
-    float b = timeit([&] { hipLaunchKernelGGL((w_row4<true>), dim3(n4 / 256), dim3(256), 0, 0, out, n4, nticks); }, 10);
-    float c = timeit([&] { hipLaunchKernelGGL((w_row16<false>), dim3(n4 / 256), dim3(256), 0, 0, out, n4, nticks); }, 10);
-    float d = timeit([&] { hipLaunchKernelGGL((w_row16<true>), dim3(n4 / 256), dim3(256), 0, 0, out, n4, nticks); }, 10);
+    float a = timeit([&] { hipLaunchKernelGGL((w_row4<false>), dim3(n4 / 256), dim3(256), 0, 0, out, n4, nticks); }, 30);
+    float b = timeit([&] { hipLaunchKernelGGL((w_row4<true>), dim3(n4 / 256), dim3(256), 0, 0, out, n4, nticks); }, 30);
+    float c = timeit([&] { hipLaunchKernelGGL((w_row16<false>), dim3(n4 / 256), dim3(256), 0, 0, out, n4, nticks); }, 30);
+    float d = timeit([&] { hipLaunchKernelGGL((w_row16<true>), dim3(n4 / 256), dim3(256), 0, 0, out, n4, nticks); }, 30);
     printf("1 Mi channels x 1024 ticks (1 GiB): row4 %.0f  row4-nt %.0f  row16 %.0f  row16-nt %.0f GB/s\n",
            bytes / a / 1e6, bytes / b / 1e6, bytes / c / 1e6, bytes / d / 1e6);
     for (int gx : {1024, 2048, 4096, 8192}) {
-        float e = timeit([&] { hipLaunchKernelGGL((w_flat<false>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 10);
-        float f = timeit([&] { hipLaunchKernelGGL((w_flat<true>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 10);
+        float e = timeit([&] { hipLaunchKernelGGL((w_flat<false>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 30);
+        float f = timeit([&] { hipLaunchKernelGGL((w_flat<true>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 30);
         printf("flat fill 1 GiB, grid %5d: plain %.0f  nt %.0f GB/s\n", gx, bytes / e / 1e6, bytes / f / 1e6);
     }
     for (int gx : {256, 512, 1024, 2048, 4096}) {
-        float e = timeit([&] { hipLaunchKernelGGL((w_chunk<4, 256>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 10);
-        float f = timeit([&] { hipLaunchKernelGGL((w_wavechunk<4, 256>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 10);
-        float g = timeit([&] { hipLaunchKernelGGL((w_wavechunk<8, 256>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 10);
-        float h = timeit([&] { hipLaunchKernelGGL((w_wavechunk<4, 1024>), dim3(gx), dim3(1024), 0, 0, (u32x4 *)out, bytes / 16); }, 10);
-        float k1 = timeit([&] { hipLaunchKernelGGL((w_wavechunk<1, 1024>), dim3(gx), dim3(1024), 0, 0, (u32x4 *)out, bytes / 16); }, 10);
+        float e = timeit([&] { hipLaunchKernelGGL((w_chunk<4, 256>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 30);
+        float f = timeit([&] { hipLaunchKernelGGL((w_wavechunk<4, 256>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 30);
+        float g = timeit([&] { hipLaunchKernelGGL((w_wavechunk<8, 256>), dim3(gx), dim3(256), 0, 0, (u32x4 *)out, bytes / 16); }, 30);
+        float h = timeit([&] { hipLaunchKernelGGL((w_wavechunk<4, 1024>), dim3(gx), dim3(1024), 0, 0, (u32x4 *)out, bytes / 16); }, 30);
+        float k1 = timeit([&] { hipLaunchKernelGGL((w_wavechunk<1, 1024>), dim3(gx), dim3(1024), 0, 0, (u32x4 *)out, bytes / 16); }, 30);
         printf("grid %5d: lane-chunk64B %.0f  wave4x256thr %.0f  wave8x256thr %.0f  wave4x1024thr %.0f  flat1024thr %.0f GB/s\n", gx,
                bytes / e / 1e6, bytes / f / 1e6, bytes / g / 1e6, bytes / h / 1e6, bytes / k1 / 1e6);
     }
-    float m = timeit([&] { (void)hipMemsetAsync(out, 0, bytes, 0); }, 10);
+    float m = timeit([&] { (void)hipMemsetAsync(out, 0, bytes, 0); }, 30);
     printf("hipMemsetAsync 1 GiB: %.0f GB/s\n", bytes / m / 1e6);
     return 0;
 }
