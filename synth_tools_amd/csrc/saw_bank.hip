@@ -432,8 +432,16 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         const unsigned long long L = Ls[0][t] + Ls[1][t] + Ls[2][t] + Ls[3][t];
         const unsigned long long U0 = Us[0][0] + Us[1][0] + Us[2][0] + Us[3][0];
         const unsigned long long I = Us[0][1] + Us[1][1] + Us[2][1] + Us[3][1];
-        uint32_t wraps = 0;                         // W(t): carries of frames before t (mod 16 matters)
-        for (uint32_t k = 0; k < t; k++) wraps += Ws[0][k] + Ws[1][k] + Ws[2][k] + Ws[3][k];
+        // W(t): carries of the frames before t (only mod 16 matters) -- exclusive prefix sum over
+        // the 64 lanes of this wave (part == 0 is exactly wave 0; lane == t)
+        const uint32_t mine = Ws[0][t] + Ws[1][t] + Ws[2][t] + Ws[3][t];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (t >= (uint32_t)o) incl += up;
+        }
+        const uint32_t wraps = incl - mine;
         const unsigned long long x = U0 + (unsigned long long)t * I - ((unsigned long long)(wraps & 15u) << 32) - L;
         const uint32_t r = (uint32_t)(x >> 4) - (nvoices << 27);
         const uint32_t f = blockIdx.x * 64u + t;
