@@ -364,6 +364,9 @@ def main():
                                    "(tick ABI), seeded note bank (splitmix64), all voices on" % (a.voices, a.frames),
                        "voices_per_gpu": a.voices, "frames_per_step": a.frames,
                        "voices_total": world * a.voices,
+                       "baseline_config": "BASELINE configs[1] (int32 phase-accumulator saw voices on 1 MI355X, "
+                                          "bit-exact) scaled from 65 536 voices (512 KiB, launch-bound: see `also`) to an "
+                                          "HBM-resident bank, the regime the %HBM-roofline metric is defined in",
                        "parallelism": "voices sharded x%d, int32 bus all-reduce (RCCL)" % world if comm else "1 GPU"},
             "max_voices_48k": int(vs / 48000),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
