@@ -196,6 +196,16 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
     out.append({"workload": "c2: saw bank, 65536 voices, 4096 frames/launch (64 JACK blocks per launch, time-parallel chunks)",
                 "value": round(65536 * 4096 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s",
                 "ms_per_step": round(ms, 5)})
+    # BASELINE config 5's per-GPU shard: 8 Mi voices over 8 GPUs = 1 Mi voices each
+    inc, st = synthetic.saw_bank(1 << 20, 0x5EED0005, tab)
+    b = sta.SawBank(1 << 20)
+    b.load(inc, st)
+    for frames in (1, 64):
+        ms = time_saw(sta, b, frames, 200, 20)
+        out.append({"workload": "c5 shard: saw bank, 1048576 voices (1/8 of 8 Mi), %d frame(s)/step" % frames,
+                    "value": round((1 << 20) * frames / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s",
+                    "ms_per_step": round(ms, 5)})
+    b.close()
     # BASELINE config 3: 1 Mi PDM channels (mod_pdm.c integer path), dither 0 and seeded
     n, nt = 1 << 20, 4096
     sp, ac = synthetic.pdm_bank(n, 0x5EED0003)

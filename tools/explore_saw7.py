@@ -8,9 +8,13 @@ n = 1 << 26
 inc, st = synthetic.saw_bank(n, 1, tab)
 b = sta.SawBank(n); b.load(inc, st)
 line = "grid=%s" % os.environ.get("SMX_SAW_CARRY_GRID", "default")
-for B in (32, 64, 1024):
-    for _ in range(3): b.run_async(B)
-    b.sync(); K = 20 if B < 1024 else 4; b.timer_start()
+import time
+for B in (32, 64):
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.03:          # steady state (clock ramp)
+        for _ in range(10): b.run_async(B)
+        b.sync()
+    K = 100; b.timer_start()
     for _ in range(K): b.run_async(B)
     ms = b.timer_stop() / K
     line += "  B=%d %8.1f us %7.0f Gs/s" % (B, ms * 1e3, n * B / ms / 1e6)
