@@ -106,9 +106,48 @@ void osc_events_kernel(smx::PmeasArrays p, const uint32_t *__restrict__ cc,
 }
 
 // (3) clock bank: the integer-divider square wave / MIDI clock of linux/clock.c:106-120,
-//     N dividers.  One lane per clock; the wave's 64 polarity bits of a frame are the
-//     compare mask, collected per lane (lane t keeps frame t) and transposed through LDS
-//     into frame-major bit matrices like the PDM bank's pulses.
+//     N dividers.  One lane per clock.  The polarity of a wave's 64 clocks is ONE 64-bit scalar
+//     mask: a frame is  roll = (phase >= hperiod)  [v_cmp -> SGPR pair],  polarity ^= roll,
+//     midi tick = roll & polarity  [two scalar ops],  phase = phase + 1 - (roll ? hperiod : 0)
+//     [v_cndmask + v_sub], and lane t keeps frame t's two masks (4 x v_writelane with a constant
+//     lane select, as in the PDM bank); tiles of 64 frames are transposed through LDS into
+//     frame-major bit matrices like the PDM bank's pulses.  7 vector instructions per 64 clock-frames.
+template <int T>
+__device__ __forceinline__ void keep_frame(uint32_t &wlo, uint32_t &whi, unsigned long long m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the masks are scalar-ALU results; the s_nop covers a mask that the compiler took straight
+    // from a vector compare (2 wait states between a VALU SGPR write and a VALU read on gfx950)
+    asm("s_nop 1\n\t"
+        "v_writelane_b32 %0, %2, %4\n\t"
+        "v_writelane_b32 %1, %3, %4"
+        : "+v"(wlo), "+v"(whi)
+        : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "n"(T));
+#else
+    (void)wlo; (void)whi; (void)m;
+#endif
+}
+
+template <int T>
+struct ClockFrames {
+    static __device__ __forceinline__ void run(uint32_t &ph, uint32_t hpm1, unsigned long long &pm,
+                                               uint32_t &plo, uint32_t &phi, uint32_t &tlo, uint32_t &thi)
+    {
+        const bool roll = ph > hpm1;                          // ph >= hperiod, clock.c:108 (unsigned compare)
+        const unsigned long long r = __ballot(roll);
+        ph -= roll ? hpm1 : 0xFFFFFFFFu;                      // (ph - hperiod) + 1, or ph + 1
+        pm ^= r;
+        keep_frame<T>(plo, phi, pm);
+        keep_frame<T>(tlo, thi, r & pm);                      // positive edge: MIDI clock 0xF8
+        ClockFrames<T + 1>::run(ph, hpm1, pm, plo, phi, tlo, thi);
+    }
+};
+template <>
+struct ClockFrames<64> {
+    static __device__ __forceinline__ void run(uint32_t &, uint32_t, unsigned long long &, uint32_t &, uint32_t &,
+                                               uint32_t &, uint32_t &) {}
+};
+
 __global__ __launch_bounds__(256)
 void clock_kernel(const uint32_t *__restrict__ hperiod, uint32_t *__restrict__ phase,
                   uint32_t *__restrict__ pol, unsigned long long *__restrict__ pol_bits,
@@ -119,21 +158,36 @@ void clock_kernel(const uint32_t *__restrict__ hperiod, uint32_t *__restrict__ p
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t c = blockIdx.x * 256u + tid;
     const bool live = c < n;
+    // a padding lane never rolls: hperiod 0 would make hpm1 wrap to "always" -- give it the longest period
     const uint32_t hp = live ? hperiod[c] : 0xFFFFFFFFu;
-    uint32_t ph = live ? phase[c] : 0u, po = live ? pol[c] : 0u;
+    uint32_t ph = live ? phase[c] : 0u;
+    const uint32_t po0 = live ? pol[c] : 0u;
+    // the mask form needs polarity in {0, 1} (clock.c's own values) and hperiod > 0 in every lane of
+    // the wave; anything else (hperiod 0 rolls every frame, other polarity words) takes the generic
+    // frames below, where polarity is only "zero / non-zero" in the bit matrices as well
+    const bool fast = __all(hp != 0 && po0 <= 1u);
+    unsigned long long pm = __ballot(po0 != 0);
+    uint32_t po = po0;
+    const uint32_t hpm1 = hp - 1;
     for (uint32_t t0 = 0; t0 < nframes; t0 += 64) {
         const uint32_t nt = min(64u, nframes - t0);
-        unsigned long long wp = 0, wt = 0;
-        for (uint32_t t = 0; t < nt; t++) {
-            const bool roll = live && ph >= hp;              // clock.c:108 (unsigned compare)
-            if (roll) { ph -= hp; po ^= 1u; }
-            const unsigned long long mp = __ballot(po != 0);
-            const unsigned long long mt = __ballot(roll && po == 1u);   // positive edge: MIDI clock 0xF8
-            if (lane == t) { wp = mp; wt = mt; }
-            ph += 1;
+        uint32_t plo = 0, phi = 0, tlo = 0, thi = 0;
+        if (nt == 64 && fast) {
+            ClockFrames<0>::run(ph, hpm1, pm, plo, phi, tlo, thi);
+        } else {
+            if (fast) po = (uint32_t)((pm >> lane) & 1);      // after full tiles of the mask form
+            for (uint32_t t = 0; t < nt; t++) {               // ragged tail / generic values
+                const bool roll = live && ph >= hp;
+                if (roll) { ph -= hp; po ^= 1u; }
+                const unsigned long long mp = __ballot(po != 0);
+                const unsigned long long mt = __ballot(roll && po == 1u);
+                if (lane == t) { plo = (uint32_t)mp; phi = (uint32_t)(mp >> 32); tlo = (uint32_t)mt; thi = (uint32_t)(mt >> 32); }
+                ph += 1;
+            }
+            pm = __ballot(po != 0);
         }
-        S[0][lane][wave] = wp;
-        S[1][lane][wave] = wt;
+        S[0][lane][wave] = ((unsigned long long)phi << 32) | plo;
+        S[1][lane][wave] = ((unsigned long long)thi << 32) | tlo;
         __syncthreads();
         // 64 rows x 4 words: one thread per (row, word)
         const uint32_t row = tid >> 2, col = tid & 3;
@@ -144,6 +198,7 @@ void clock_kernel(const uint32_t *__restrict__ hperiod, uint32_t *__restrict__ p
         }
         __syncthreads();
     }
+    if (fast) po = (uint32_t)((pm >> lane) & 1);
     if (live) { phase[c] = ph; pol[c] = po; }
 }
 

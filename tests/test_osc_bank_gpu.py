@@ -116,3 +116,30 @@ def test_clock_bank_parity(smx, orc, n):
     ghp, gph, gpo = bank.read()
     assert np.array_equal(gph, ph) and np.array_equal(gpo, po) and np.array_equal(ghp, hp)
     bank.close()
+
+
+def test_clock_bank_loaded_state(smx, orc):
+    """Loaded phases beyond the half period (several rolls in a row), polarity words other than
+    0/1 (only "zero / non-zero" and "== 1" matter: linux/clock.c:110-116 as restated), waves with and
+    without an hperiod of 0, tiles of exactly 64 frames and ragged ones."""
+    n = 4096
+    rng = np.random.default_rng(9)
+    hp = rng.integers(1, 50, n).astype(np.uint32)
+    hp[64:128] = rng.integers(0, 3, 64)                        # one wave with zeros
+    hp[1000] = 0xFFFFFFFF
+    ph = rng.integers(0, 400, n).astype(np.int32)
+    ph[5] = -7                                                 # unsigned compare: rolls at once
+    po = rng.integers(0, 2, n).astype(np.uint32)
+    po[256:320] = rng.integers(0, 6, 64)                       # one wave with other polarity words
+    bank = smx.ClockBank(n)
+    bank.load(hperiod=hp, phase=ph, pol=po)
+    words = (n + 31) // 32
+    for nf in (64, 128, 3, 64, 191):
+        gp, gt = bank.run(nf)
+        wp, wt = np.zeros(nf * words, np.uint32), np.zeros(nf * words, np.uint32)
+        orc.orc_clock_run(hp, ph, po, n, nf, wp, wt)
+        assert np.array_equal(gp.reshape(-1), wp), nf
+        assert np.array_equal(gt.reshape(-1), wt), nf
+    _, gph, gpo = bank.read()
+    assert np.array_equal(gph, ph) and np.array_equal(gpo, po)
+    bank.close()
