@@ -45,11 +45,12 @@ def test_reference_graphs(smx, orc):
     bank.close()
 
 
+@pytest.mark.parametrize("n_nodes", [2, 4, 5, 8, 9, 12, 32])     # every unroll bucket (4, 8, 16, 32 nodes)
 @pytest.mark.parametrize("n", [1, 255, 257, 5000])
-def test_random_chains(smx, orc, n):
+def test_random_chains(smx, orc, n, n_nodes):
     from synth_tools_amd import PROC_ACC, PROC_EDGE, cproc_input
-    rng = np.random.default_rng(n)
-    n_inputs, n_nodes = 3, 12
+    rng = np.random.default_rng(n * 100 + n_nodes)
+    n_inputs = 3
     nodes = []
     for k in range(n_nodes):
         src = cproc_input(int(rng.integers(0, n_inputs))) if k == 0 or rng.random() < 0.3 else int(rng.integers(0, k))
