@@ -80,10 +80,9 @@ void osc_events_kernel(smx::PmeasArrays p, const uint32_t *__restrict__ cc,
     uint32_t sub = p.sub[c];
     uint32_t avg[2] = {p.avg0[c], p.avg1[c]}, npub[2] = {p.num0[c], p.num1[c]};
     const uint32_t max = 1u << log_max;
-    for (uint32_t e = 0; e < nevents; e++) {
-        if (valid_bits && !((valid_bits[(size_t)e * words_per_row + (c >> 5)] >> (c & 31)) & 1)) continue;
+    // one event of the ISR for this oscillator
+    auto event = [&](uint32_t now) __attribute__((always_inline)) {
         sub ^= 1;                                            // sub-osc divide by two, mod_osc.c:65
-        const uint32_t now = cc[(size_t)e * n + c];
         const uint32_t meas = now - last_cc;                 // pmeas.h:67-68
         last_cc = now;
         const uint32_t accu1 = accu + meas;
@@ -100,6 +99,26 @@ void osc_events_kernel(smx::PmeasArrays p, const uint32_t *__restrict__ cc,
             num = 1;
             accu = meas;
         }
+    };
+    // the timestamps (and valid words) of 8 events are requested together, ahead of the state
+    // machine that consumes them one by one (one load per event inside the loop: 107 us for
+    // 1 Mi oscillators x 64 events)
+    const uint32_t vword = c >> 5, vbit = c & 31;
+    uint32_t e = 0;
+    for (; e + 8 <= nevents; e += 8) {
+        uint32_t now[8], vw[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            now[k] = cc[(size_t)(e + k) * n + c];
+            vw[k] = valid_bits ? valid_bits[(size_t)(e + k) * words_per_row + vword] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((vw[k] >> vbit) & 1) event(now[k]);
+    }
+    for (; e < nevents; e++) {
+        if (valid_bits && !((valid_bits[(size_t)e * words_per_row + vword] >> vbit) & 1)) continue;
+        event(cc[(size_t)e * n + c]);
     }
     p.write[c] = write; p.num[c] = num; p.accu[c] = accu; p.last_cc[c] = last_cc; p.sub[c] = sub;
     p.avg0[c] = avg[0]; p.avg1[c] = avg[1]; p.num0[c] = npub[0]; p.num1[c] = npub[1];
