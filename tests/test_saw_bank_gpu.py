@@ -277,11 +277,15 @@ def test_long_blocks_grow_the_bus(smx, orc, inc_table):
 def test_randomised_block_sequences(smx, orc, inc_table):
     """Seeded fuzz: random bank sizes around every kernel-selection threshold, random block
     lengths, random activity, with MIDI events and bulk reloads between blocks."""
-    rng = np.random.default_rng(0xF022)
+    import os
+    # SMX_FUZZ_SEED / SMX_FUZZ_ROUNDS widen the run for a soak (defaults: one round, fixed seed)
+    seed = int(os.environ.get("SMX_FUZZ_SEED", "0xF022"), 0)
+    rounds = int(os.environ.get("SMX_FUZZ_ROUNDS", "1"))
+    rng = np.random.default_rng(seed)
     sizes = [1, 63, 64, 65, 255, 1023, 1024, 1025, 4096, 65535, 65537, (1 << 20) - 1, (1 << 20), (1 << 20) + 1]
-    for trial in range(14):
-        n = sizes[trial]
-        inc, state = synthetic.saw_bank(n, 0xF000 + trial, inc_table, active_fraction=float(rng.choice([0.0, 0.3, 1.0])))
+    for trial in range(14 * rounds):
+        n = sizes[trial % 14]
+        inc, state = synthetic.saw_bank(n, 0xF000 + trial + seed, inc_table, active_fraction=float(rng.choice([0.0, 0.3, 1.0])))
         if trial % 3 == 0:                                     # arbitrary (non-table) increments and phases
             inc = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
         bank = smx.SawBank(n)
@@ -292,9 +296,14 @@ def test_randomised_block_sequences(smx, orc, inc_table):
         for _ in range(6):
             nf = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 257]))
             if n <= 4096 and rng.random() < 0.5:
-                for _ in range(int(rng.integers(1, 20))):
-                    msg = np.array([0x90, int(rng.integers(0, 128)), int(rng.integers(0, 2)) * 64], np.uint8)
-                    bank.midi_event(msg)
+                msgs = [np.array([0x90, int(rng.integers(0, 128)), int(rng.integers(0, 2)) * 64], np.uint8)
+                        for _ in range(int(rng.integers(1, 20)))]
+                if rng.random() < 0.5:
+                    bank.midi_events(np.stack(msgs))                # the block's events in one call
+                else:
+                    for msg in msgs:
+                        bank.midi_event(msg)
+                for msg in msgs:
                     orc.orc_midi_event(n2v, inc, n, msg, 3)
             r = rng.random()
             if r < 0.2:                                        # bulk reload of the increments only
