@@ -107,8 +107,10 @@ void pdm_bank_kernel(const uint32_t *__restrict__ setpoint,
                      uint32_t nticks,
                      uint32_t n)                  // real channels; the rest is padding
 {
-    __shared__ unsigned long long S[64][17];      // [tick][wave], padded
-    __shared__ unsigned long long VM[16];         // per wave: which lanes are real channels
+    // [buffer][tick][wave], padded.  Two buffers: tile k is written to S[k & 1], then ONE barrier,
+    // then read; the buffer tile k+1 writes was last read in tile k-1, before every thread reached
+    // tile k's barrier -- so no second barrier per tile is needed.
+    __shared__ unsigned long long S[2][64][17];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t row = tid >> 4, col = tid & 15; // flush: 16 lanes x 8 B = one 128-B row
@@ -121,6 +123,7 @@ void pdm_bank_kernel(const uint32_t *__restrict__ setpoint,
         sp_next = setpoint[blockIdx.x * 1024u + tid];
         a_next = accu[blockIdx.x * 1024u + tid];
     }
+    uint32_t buf = 0;
     for (uint32_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const uint32_t ch = blk * 1024u + tid;
         const uint32_t sp = sp_next;
@@ -128,20 +131,21 @@ void pdm_bank_kernel(const uint32_t *__restrict__ setpoint,
         const uint32_t nb = min(blk + gridDim.x, nblocks - 1) * 1024u + tid;   // last trip re-reads its own
         sp_next = setpoint[nb];
         a_next = accu[nb];
-        // padding channels (setpoint 0) would still pulse under dither: mask them out
-        const unsigned long long vm = __ballot(ch < n);
-        if (lane == 0) VM[wave] = vm;
+        // padding channels (setpoint 0) would still pulse under dither: the storing thread masks
+        // the lanes of "its" wave (col) that lie beyond the last real channel
+        const uint32_t base = blk * 1024u + col * 64u;
+        const unsigned long long vmask = base + 64u <= n ? ~0ull : (base < n ? (1ull << (n - base)) - 1ull : 0ull);
 
         for (uint32_t t0 = 0; t0 < nticks; t0 += 64) {
             const uint32_t nt = min(64u, nticks - t0);
             uint32_t wlo = 0, whi = 0;
             if (nt == 64) PdmTicks<0, DITHER>::run(a, sp, dither + t0, wlo, whi);
             else          PdmRagged<32, 0, DITHER>::run(nt, a, sp, dither + t0, wlo, whi);   // ragged tail
-            S[lane][wave] = ((unsigned long long)whi << 32) | wlo;
+            S[buf][lane][wave] = ((unsigned long long)whi << 32) | wlo;
             __syncthreads();
             if (row < nt)
-                bits64[(size_t)(t0 + row) * words64_per_tick + blk * 16u + col] = S[row][col] & VM[col];
-            __syncthreads();
+                bits64[(size_t)(t0 + row) * words64_per_tick + blk * 16u + col] = S[buf][row][col] & vmask;
+            buf ^= 1;
         }
         accu[ch] = a;
     }
