@@ -6,6 +6,7 @@ TAG=${1:-r01}
 shift || true
 ARGS="${@:---steps 50 --warmup 5 --no-also --no-cpu}"
 OUT=$PWD/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD

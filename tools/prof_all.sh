@@ -6,6 +6,7 @@
 set -e
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_${TAG}_all
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD

@@ -19,7 +19,7 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
 for leg in ("trace", "fetch", "write"):
     p = os.path.join(src, "bench_%s.json" % leg)
@@ -28,7 +28,7 @@ for leg in ("trace", "fetch", "write"):
 
 
 def pmc(leg, counter):
-    f = glob.glob(os.path.join(src, "pmc_" + leg, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, "pmc_" + leg, "*", "*counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:

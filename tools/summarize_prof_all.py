@@ -14,14 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "prof_%s_all" % tag)
 dst = os.path.join(ROOT, "profiles")
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copy(stats, os.path.join(dst, tag + "_all_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(dst, tag + "_bench_full_under_trace.json"))
 dur = {r["Name"]: (float(r["AverageNs"]), int(r["Calls"])) for r in csv.DictReader(open(stats))}
 
 
 def pmc(leg, counter):
-    f = glob.glob(os.path.join(src, "pmc_" + leg, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, "pmc_" + leg, "*", "*counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
