@@ -120,6 +120,18 @@ int smx_bank_run(smx_bank *b, float *vec, int32_t *bus, int n);
 #define SMX_BLOCK_PIPELINED 1
 int smx_bank_set_block_mode(smx_bank *b, int mode);
 
+/* How blocks of more than 32 frames of a big bank (>= 2^20 voices, >= 2^31 voice-samples per launch)
+ * find the 32-bit wraps of the phases -- the only non-linear part of sum_tick_saw
+ * (linux/synth.c:172-179); every form gives the same bits.  STEPPING adds inc frame by frame and
+ * counts the carry-outs.  EVENTS locates each wrap directly (first at floor(~phase/inc), then every
+ * floor((2^32-1)/inc) or one more frames): much less work for banks of mostly low voices, more for
+ * banks of high ones.  AUTO (default) keeps a statistic of the increments on the device and picks
+ * per launch; the first long block after smx_bank_load(inc) steps. */
+#define SMX_FORM_AUTO     0
+#define SMX_FORM_STEPPING 1
+#define SMX_FORM_EVENTS   2
+int smx_bank_set_block_form(smx_bank *b, int form);
+
 /* Asynchronous form: enqueue one block of n frames on the bank's stream and
  * leave the int32 bus in device memory (smx_bank_bus_dev).  No host sync. */
 int   smx_bank_run_async(smx_bank *b, int n);

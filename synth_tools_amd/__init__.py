@@ -94,6 +94,7 @@ ABI = [
     ("smx_bank_midi_events", C.c_int, [_P, _u8, C.c_size_t]),
     ("smx_bank_run", C.c_int, [_P, _P, _P, C.c_int]),
     ("smx_bank_set_block_mode", C.c_int, [_P, C.c_int]),
+    ("smx_bank_set_block_form", C.c_int, [_P, C.c_int]),
     ("smx_bank_run_async", C.c_int, [_P, C.c_int]),
     ("smx_bank_bus_dev", _P, [_P]),
     ("smx_bank_sync", C.c_int, [_P]),
@@ -244,6 +245,10 @@ class SawBank:
 
     def set_block_mode(self, pipelined):
         _check(lib().smx_bank_set_block_mode(self._h, 1 if pipelined else 0), "smx_bank_set_block_mode")
+
+    def set_block_form(self, form):
+        """0 auto, 1 stepping, 2 wrap events (long blocks of big banks; same bits either way)."""
+        _check(lib().smx_bank_set_block_form(self._h, form), "smx_bank_set_block_form")
 
     def midi_event(self, msg):
         m = np.ascontiguousarray(msg, np.uint8)

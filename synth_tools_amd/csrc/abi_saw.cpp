@@ -100,6 +100,7 @@ struct smx_bank {
     // pipelined block mode (smx_bank_set_block_mode): the bus of block k is copied to pinned
     // memory behind its kernel and handed out by the call that launches block k+1
     int block_mode = 0;
+    int block_form = SMX_FORM_AUTO;              // smx_bank_set_block_form
     int32_t *h_pipe[2] = {nullptr, nullptr};
     uint32_t pipe_cap = 0;
     hipEvent_t ev_pipe[2] = {nullptr, nullptr};
@@ -261,6 +262,9 @@ extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *s
     if (inc) {
         SMX_HIP(hipMemcpy(b->d_inc, inc, (size_t)b->n * 4, hipMemcpyHostToDevice));
         b->free_map.load(inc, b->n);
+        // new increments: the statistic that picks the long-block form is void (stepping until the
+        // next long block has measured the new bank)
+        if (b->d_scratch) SMX_HIP(hipMemsetAsync(b->d_scratch, 0, smx::saw_scratch_header_bytes(), b->stream));
     }
     if (state)
         SMX_HIP(hipMemcpy(b->d_state0, state, (size_t)b->n * 4, hipMemcpyHostToDevice));
@@ -428,7 +432,7 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
     rv = bank_bus_advance(b, (uint32_t)n, &bi, &bnext);
     if (rv) return rv;
     rv = smx::launch_saw_bank(b->d_inc, b->d_state0, b->d_bus[bi], b->d_bus[bnext], b->n_pad, (uint32_t)n,
-                              b->elapsed, b->d_scratch, b->stream);
+                              b->elapsed, b->d_scratch, b->block_form, b->stream);
     if (rv) return rv;
     b->elapsed += (uint32_t)n;             // mod 2^32, like the phases
     b->bus_zeroed[bi] = 0;                 // now holds this block's sums
@@ -544,6 +548,16 @@ extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
     SMX_HIP(hipStreamSynchronize(b->stream));
     if (bus) memcpy(bus, b->h_bus, (size_t)n * 4);
     if (vec) for (int i = 0; i < n; i++) vec[i] = bus_to_float(b->h_bus[i]);
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_set_block_form(smx_bank *b, int form)
+{
+    if (!b || (form != SMX_FORM_AUTO && form != SMX_FORM_STEPPING && form != SMX_FORM_EVENTS)) {
+        set_error("smx_bank_set_block_form: form %d", form);
+        return SMX_E_ARG;
+    }
+    b->block_form = form;
     return SMX_OK;
 }
 

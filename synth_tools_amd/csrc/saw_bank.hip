@@ -61,7 +61,13 @@ struct SawPartial {
     unsigned long long L[64];     // sum over voices of (u_v(t) & 15)
     unsigned long long U0, I;     // sum u_v(t0), sum inc_v
     uint32_t W[64];               // carries out of the phase add at frame t (t -> t+1)
+    uint32_t maxinc, pad_;        // largest increment seen (statistic for the next launch's formulation)
 };
+// The first bytes of the scratch area: which form of the carry kernel the next long-block launch
+// runs (0: stepping, 1: wrap events).  Written by the finalize kernel from the bank's statistics,
+// read by both forms at their start -- the one that is not selected returns at once.  Both forms
+// are exact for any bank; the flag only steers speed, so a stale value is harmless.
+constexpr size_t SAW_SCRATCH_HEADER = 64;
 
 // SLOT: instead of one atomic per frame per workgroup on the bus itself (same-address integer
 // atomics serialise at ~20 ns: 2048 workgroups ending together cost 40 us), the workgroup adds
@@ -289,28 +295,45 @@ __device__ __forceinline__ uint32_t carry_step4(uint32_t &u0, uint32_t &u1, uint
 
 // MULTI: more than one 64-frame chunk per launch (blockIdx.y).
 // TC: frames computed per chunk (64, or 32 for single-chunk blocks of 17..32 frames).
-template <bool NT, bool MULTI, int TC>
+// EVENTS: the wraps are not found by stepping the phases but located directly (TC == 64 only):
+//   first wrap of a voice at frame  n1 = floor(~u / inc)            (u: offset-binary phase at chunk start)
+//   then gaps of                    Q + (r <= R),  Q = floor((2^32-1)/inc),  R = 2^32-1 - Q*inc
+//   residual                        r <- r + (r <= R ? E : E - inc),  E = inc-1-R,  r0 = u + (n1+1)*inc
+// ~8 vector instructions and one LDS add per WRAP (plus two 32-bit divisions per voice) instead of
+// 1.5 per voice-SAMPLE: a piano-range bank wraps 1.1 times per voice in 64 frames -- 64 Mi voices
+// x 64 frames 236 -> 18x us -- but the loop runs as long as the busiest voice of the wave, so banks
+// with many high voices are slower this way (all voices at 12 wraps: 3x).  The finalize kernel
+// keeps the statistic that picks the form (mode_flag; see SAW_SCRATCH_HEADER).
+template <bool NT, bool MULTI, int TC, bool EVENTS>
 __global__ __launch_bounds__(256)
 void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
-                           SawPartial *__restrict__ partial, uint32_t ngroups, uint32_t tbase)
+                           SawPartial *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
+                           const uint32_t *__restrict__ mode_flag)
 {
+    static_assert(!EVENTS || TC == 64, "the event form is built for 64-frame chunks");
     __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
     __shared__ unsigned long long S[2];            // U0, I
+    __shared__ uint32_t MX;                        // largest increment
+    if (mode_flag && (*mode_flag != 0u) != EVENTS) return;     // the other form runs this launch
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t t0 = tbase + (MULTI ? blockIdx.y * 64u : 0u);   // phase offset of this chunk
     for (uint32_t i = tid; i < 64 * 65; i += 256) (&M[0][0])[i] = 0;
     H[tid] = 0;
     if (tid < 2) S[tid] = 0;
+    if (tid == 0) MX = 0;
     __syncthreads();
 
-    uint32_t cnt[TC];                              // per-lane carry counts (voices 0/1)
-    uint32_t W[32];                                // wave-uniform counts (voices 2/3): frames t | t+32 << 16
+    uint32_t cnt[EVENTS ? 1 : TC];                 // per-lane carry counts (voices 0/1)
+    uint32_t W[EVENTS ? 1 : 32];                   // wave-uniform counts (voices 2/3): frames t | t+32 << 16
+    if constexpr (!EVENTS) {
 #pragma unroll
-    for (int t = 0; t < TC; t++) cnt[t] = 0;
+        for (int t = 0; t < TC; t++) cnt[t] = 0;
 #pragma unroll
-    for (int t = 0; t < 32; t++) W[t] = 0;
+        for (int t = 0; t < 32; t++) W[t] = 0;
+    }
     unsigned long long sumU = 0, sumI = 0;
+    uint32_t mx = 0;
 
     // ngroups is a multiple of 256 (n_pad of 1024): whole workgroup rows, so the trip count is
     // wave-uniform and the scalar counters W stay in SGPRs
@@ -342,23 +365,62 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         atomicAdd(&H[((u1 & 15) << 4) | (a.y & 15)], 1u);
         atomicAdd(&H[((u2 & 15) << 4) | (a.z & 15)], 1u);
         atomicAdd(&H[((u3 & 15) << 4) | (a.w & 15)], 1u);
+        mx = max(max(mx, a.x), max(max(a.y, a.z), a.w));
+        if constexpr (EVENTS) {
+            const uint32_t vi[4] = {a.x, a.y, a.z, a.w}, vu[4] = {u0, u1, u2, u3};
+            uint32_t et[4], er[4], eq[4], erm[4], ee[4];
+            bool more = false;
 #pragma unroll
-        for (int t = 0; t < TC; t++) {
-            const uint32_t c = carry_step4(u0, u1, u2, u3, a.x, a.y, a.z, a.w, cnt[t]);
-            W[t & 31] += (t < 32) ? c : (c << 16);
+            for (int k = 0; k < 4; k++) {
+                const uint32_t d = vi[k] ? vi[k] : 1u;
+                const uint32_t n1 = ~vu[k] / d;
+                eq[k] = 0xFFFFFFFFu / d;
+                erm[k] = 0xFFFFFFFFu - eq[k] * d;
+                ee[k] = d - 1u - erm[k];
+                eq[k] = min(eq[k], 1u << 30);              // a gap beyond the chunk is as good as any other:
+                                                           // keeps et + gap from wrapping (inc == 1: Q = 2^32-1)
+                er[k] = vu[k] + (n1 + 1u) * d;             // mod 2^32: the phase right after the first wrap
+                et[k] = vi[k] ? n1 : 0xFFFFFFFFu;          // off: parked, never wraps
+                more |= et[k] < 64u;
+            }
+            // every gap is at least one frame, so 64 rounds always suffice: the bound makes the
+            // loop finite whatever the data
+            for (int round = 0; round < 64 && __any(more); round++) {
+                more = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (et[k] < 64u) {
+                        atomicAdd(&M[et[k]][lane], 1u);     // own column: no lane ever shares an address
+                        const bool c = er[k] <= erm[k];
+                        et[k] += eq[k] + (c ? 1u : 0u);
+                        er[k] += c ? ee[k] : ee[k] - vi[k];
+                        more |= et[k] < 64u;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < TC; t++) {
+                const uint32_t c = carry_step4(u0, u1, u2, u3, a.x, a.y, a.z, a.w, cnt[t]);
+                W[t & 31] += (t < 32) ? c : (c << 16);
+            }
         }
     }
 
-    // per-lane counts -> M[t][lane]; per-wave scalar counts -> M[t][64]
+    if constexpr (!EVENTS) {
+        // per-lane counts -> M[t][lane]; per-wave scalar counts -> M[t][64]
 #pragma unroll
-    for (int t = 0; t < TC; t++) atomicAdd(&M[t][lane], cnt[t]);
-    if (lane == 0) {
+        for (int t = 0; t < TC; t++) atomicAdd(&M[t][lane], cnt[t]);
+        if (lane == 0) {
 #pragma unroll
-        for (int t = 0; t < 32; t++) {
-            atomicAdd(&M[t][64], W[t] & 0xFFFFu);
-            atomicAdd(&M[t + 32][64], W[t] >> 16);
+            for (int t = 0; t < 32; t++) {
+                atomicAdd(&M[t][64], W[t] & 0xFFFFu);
+                atomicAdd(&M[t + 32][64], W[t] >> 16);
+            }
         }
     }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if (lane == 0) atomicMax(&MX, mx);
     for (int o = 32; o > 0; o >>= 1) { sumU += __shfl_xor(sumU, o); sumI += __shfl_xor(sumI, o); }
     if (lane == 0) { atomicAdd(&S[0], sumU); atomicAdd(&S[1], sumI); }
     __syncthreads();
@@ -388,7 +450,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         l += __shfl_xor(l, 2);
         if (q == 0) atomicAdd(&out->L[t], l);
     }
-    if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicAdd(&out->I, S[1]); }
+    if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicAdd(&out->I, S[1]); atomicMax(&out->maxinc, MX); }
 }
 
 // One workgroup per 64-frame chunk: add the chunk's slots (and clear them for the next
@@ -397,10 +459,10 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
 __global__ __launch_bounds__(256)
 void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
                               int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
-                              uint32_t nframes, uint32_t nvoices)
+                              uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag)
 {
     __shared__ unsigned long long Ls[4][64], Us[4][2];
-    __shared__ uint32_t Ws[4][64];
+    __shared__ uint32_t Ws[4][64], Mx[4];
     const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
     SawPartial *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
     // all loads first (16 independent ones per thread in flight), then the clearing stores
@@ -414,19 +476,22 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         uv[k] = (t == 0) ? q->U0 : 0ull;
         iv[k] = (t == 0) ? q->I : 0ull;
     }
+    uint32_t mxv[SAW_SLOTS / 4];
+#pragma unroll
+    for (int k = 0; k < SAW_SLOTS / 4; k++) mxv[k] = (t == 0) ? p[part + 4 * k].maxinc : 0u;
     unsigned long long l = 0, u0 = 0, ii = 0;
-    uint32_t w = 0;
+    uint32_t w = 0, mx = 0;
 #pragma unroll
     for (int k = 0; k < SAW_SLOTS / 4; k++) {
         SawPartial *q = p + part + 4 * k;
-        l += lv[k]; w += wv[k]; u0 += uv[k]; ii += iv[k];
+        l += lv[k]; w += wv[k]; u0 += uv[k]; ii += iv[k]; mx = max(mx, mxv[k]);
         q->L[t] = 0;
         q->W[t] = 0;
-        if (t == 0) { q->U0 = 0; q->I = 0; }
+        if (t == 0) { q->U0 = 0; q->I = 0; q->maxinc = 0; }
     }
     Ls[part][t] = l;
     Ws[part][t] = w;
-    if (t == 0) { Us[part][0] = u0; Us[part][1] = ii; }
+    if (t == 0) { Us[part][0] = u0; Us[part][1] = ii; Mx[part] = mx; }
     __syncthreads();
     if (part == 0) {
         const unsigned long long L = Ls[0][t] + Ls[1][t] + Ls[2][t] + Ls[3][t];
@@ -448,6 +513,15 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         if (f < nframes) {
             bus[f] = (int32_t)r;
             bus_next[f] = 0;                        // same contract as saw_bank_kernel
+        }
+        // Form of the next long-block launch: wrap events pay while no voice wraps more than ~6
+        // times per 64 frames (inc < 6.5 * 2^26: up to MIDI note 110 at 48 kHz) and the bank's mean
+        // is at most 2 wraps per voice (sum of inc <= voices * 2^27).  Measured on 64 Mi voices x
+        // 64 frames (stepping: 236 us): piano-range bank 18x us, all voices at 2 wraps 123 us, at 6
+        // wraps 269 us, 1 % of the voices at 12 wraps 243 us, all at 12 wraps 750 us.
+        if (blockIdx.x == 0 && t == 0 && mode_flag) {
+            const uint32_t m = max(max(Mx[0], Mx[1]), max(Mx[2], Mx[3]));
+            *mode_flag = (m < (13u << 25) && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
         }
     }
 }
@@ -586,14 +660,16 @@ int launch_vw(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
 
 namespace smx {
 
+size_t saw_scratch_header_bytes() { return SAW_SCRATCH_HEADER; }
+
 size_t saw_scratch_bytes(uint32_t max_frames)
 {
-    return (size_t)SAW_SLOTS * ((max_frames + 63) / 64 + 1) * sizeof(SawPartial);
+    return SAW_SCRATCH_HEADER + (size_t)SAW_SLOTS * ((max_frames + 63) / 64 + 1) * sizeof(SawPartial);
 }
 
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
-                    void *d_scratch, hipStream_t stream)
+                    void *d_scratch, int long_block_form, hipStream_t stream)
 {
     if (n_pad == 0 || (n_pad & 1023) || nframes == 0) {
         set_error("launch_saw_bank: n_pad=%u nframes=%u", n_pad, nframes);
@@ -618,17 +694,32 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
         // (banks that would need more workgroups than the scratch holds use the direct form)
         const uint32_t trips = (ngroups + gx * 256u - 1) / (gx * 256u);
         if (trips <= 400 && (size_t)SAW_SLOTS * gy * sizeof(SawPartial) <= saw_scratch_bytes(nframes)) {
-            auto *part = static_cast<SawPartial *>(d_scratch);     // all zero between launches
-#define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_)                                                             \
-    hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_>), dim3(gx, gy), dim3(256), 0, stream, \
-                       d_inc, d_state_in, part, ngroups, tbase)
+            auto *flag = static_cast<uint32_t *>(d_scratch);
+            auto *part = reinterpret_cast<SawPartial *>(static_cast<char *>(d_scratch) + SAW_SCRATCH_HEADER);   // all zero between launches
+            const bool no_events = long_block_form == SMX_FORM_STEPPING;
+            const bool force_events = long_block_form == SMX_FORM_EVENTS;
+#define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_, EV_, FLAG_)                                                      \
+    hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, EV_>), dim3(gx, gy), dim3(256), 0, stream, \
+                       d_inc, d_state_in, part, ngroups, tbase, FLAG_)
             const bool nt = n_pad >= (1u << 24);
-            if (gy > 1)             { if (nt) SMX_CARRY_LAUNCH(true, true, 64);  else SMX_CARRY_LAUNCH(false, true, 64); }
-            else if (nframes > 32)  { if (nt) SMX_CARRY_LAUNCH(true, false, 64); else SMX_CARRY_LAUNCH(false, false, 64); }
-            else                    { if (nt) SMX_CARRY_LAUNCH(true, false, 32); else SMX_CARRY_LAUNCH(false, false, 32); }
+            if (nframes > 32) {
+                // 64-frame chunks: both forms are queued, the device-side flag picks one (the other
+                // returns at once); the finalize kernel refreshes the flag from this launch's statistics
+                const uint32_t *f = (no_events || force_events) ? nullptr : flag;
+                if (!force_events) {
+                    if (gy > 1) { if (nt) SMX_CARRY_LAUNCH(true, true, 64, false, f);  else SMX_CARRY_LAUNCH(false, true, 64, false, f); }
+                    else        { if (nt) SMX_CARRY_LAUNCH(true, false, 64, false, f); else SMX_CARRY_LAUNCH(false, false, 64, false, f); }
+                }
+                if (!no_events) {
+                    if (gy > 1) { if (nt) SMX_CARRY_LAUNCH(true, true, 64, true, f);  else SMX_CARRY_LAUNCH(false, true, 64, true, f); }
+                    else        { if (nt) SMX_CARRY_LAUNCH(true, false, 64, true, f); else SMX_CARRY_LAUNCH(false, false, 64, true, f); }
+                }
+            } else {
+                if (nt) SMX_CARRY_LAUNCH(true, false, 32, false, nullptr); else SMX_CARRY_LAUNCH(false, false, 32, false, nullptr);
+            }
 #undef SMX_CARRY_LAUNCH
             hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
-                               d_bus_next, nframes, n_pad);
+                               d_bus_next, nframes, n_pad, flag);
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         }
@@ -660,7 +751,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     // slots need one SawPartial row per 64-frame chunk in the scratch
     SawPartial *part = nullptr;
     if (d_scratch && (size_t)SAW_SLOTS * ((nframes + 63) / 64) * sizeof(SawPartial) <= saw_scratch_bytes(nframes))
-        part = static_cast<SawPartial *>(d_scratch);
+        part = reinterpret_cast<SawPartial *>(static_cast<char *>(d_scratch) + SAW_SCRATCH_HEADER);
     if (n_pad >= (1u << 24))
         return launch_vw<4, true>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, stream);
     if (n_pad >= (1u << 20))
