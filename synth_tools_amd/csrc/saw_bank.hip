@@ -315,6 +315,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
     __shared__ unsigned long long S[2];            // U0, I
     __shared__ uint32_t MX;                        // largest increment
+    __shared__ uint2 EL[EVENTS ? 4 * 256 : 1];     // EVENTS: per wave, the (phase, inc) of the voices that wrap
     if (mode_flag && (*mode_flag != 0u) != EVENTS) return;     // the other form runs this launch
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t t0 = tbase + (MULTI ? blockIdx.y * 64u : 0u);   // phase offset of this chunk
@@ -367,22 +368,48 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         atomicAdd(&H[((u3 & 15) << 4) | (a.w & 15)], 1u);
         mx = max(max(mx, a.x), max(max(a.y, a.z), a.w));
         if constexpr (EVENTS) {
+            // (1) Which voices wrap in this chunk at all?  u + 64*inc >= 2^32.  In a piano-range bank
+            //     more than half do not, and they need neither the divisions nor the loop: the wave
+            //     compacts the (u, inc) pairs of its wrapping voices into its own LDS list ...
             const uint32_t vi[4] = {a.x, a.y, a.z, a.w}, vu[4] = {u0, u1, u2, u3};
-            uint32_t et[4], er[4], eq[4], erm[4], ee[4];
+            uint2 *list = &EL[(tid >> 6) * 256];
+            uint32_t nw = 0;                                  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool w = (vi[k] >> 26) != 0u || vu[k] + (vi[k] << 6) < vu[k];
+                const unsigned long long m = __ballot(w);
+                const uint32_t pos = nw + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (w) list[pos] = make_uint2(vu[k], vi[k]);
+                nw += (uint32_t)__builtin_popcountll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // (2) ... and every lane takes entries lane, lane + 64, ...: the same number of wrapping
+            //     voices per lane (+-1) whatever their place in the bank.
+            uint32_t ei[4], et[4], er[4], eq[4], erm[4], ee[4];
             bool more = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t d = vi[k] ? vi[k] : 1u;
-                const uint32_t n1 = ~vu[k] / d;
-                eq[k] = 0xFFFFFFFFu / d;
-                erm[k] = 0xFFFFFFFFu - eq[k] * d;
-                ee[k] = d - 1u - erm[k];
-                eq[k] = min(eq[k], 1u << 30);              // a gap beyond the chunk is as good as any other:
-                                                           // keeps et + gap from wrapping (inc == 1: Q = 2^32-1)
-                er[k] = vu[k] + (n1 + 1u) * d;             // mod 2^32: the phase right after the first wrap
-                et[k] = vi[k] ? n1 : 0xFFFFFFFFu;          // off: parked, never wraps
-                more |= et[k] < 64u;
+                et[k] = 0xFFFFFFFFu; ei[k] = er[k] = eq[k] = erm[k] = ee[k] = 0;
+                if (64u * k < nw) {                           // wave-uniform: empty slots cost nothing
+                    const uint32_t e = lane + 64u * k;
+                    const uint2 en = list[e < nw ? e : 0u];
+                    const uint32_t d = en.y;                  // > 0: an off voice never wraps
+                    const uint32_t n1 = ~en.x / d;
+                    eq[k] = 0xFFFFFFFFu / d;
+                    erm[k] = 0xFFFFFFFFu - eq[k] * d;
+                    ee[k] = d - 1u - erm[k];
+                    eq[k] = min(eq[k], 1u << 30);             // a gap beyond the chunk is as good as any other:
+                                                              // keeps et + gap from wrapping (inc == 1: Q = 2^32-1)
+                    er[k] = en.x + (n1 + 1u) * d;             // mod 2^32: the phase right after the first wrap
+                    ei[k] = d;
+                    if (e < nw) et[k] = n1;
+                    more |= et[k] < 64u;
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // list is free for the next row
+            __builtin_amdgcn_wave_barrier();
             // every gap is at least one frame, so 64 rounds always suffice: the bound makes the
             // loop finite whatever the data
             for (int round = 0; round < 64 && __any(more); round++) {
@@ -393,7 +420,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
                         atomicAdd(&M[et[k]][lane], 1u);     // own column: no lane ever shares an address
                         const bool c = er[k] <= erm[k];
                         et[k] += eq[k] + (c ? 1u : 0u);
-                        er[k] += c ? ee[k] : ee[k] - vi[k];
+                        er[k] += c ? ee[k] : ee[k] - ei[k];
                         more |= et[k] < 64u;
                     }
                 }
