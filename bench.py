@@ -175,8 +175,10 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
         out.append({"workload": "saw bank, %d voices, %d frames/step" % (voices, frames),
                     "value": round(vs / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
                     "hbm_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                    # vector ops per voice-sample: 2.5 (direct) / 1.5 + 1 scalar (carry formulation)
-                    "formulation": "carry" if frames > 16 and voices * frames >= 1 << 31 else "direct",
+                    # vector ops per voice-sample: 2.5 (direct) / 1.5 + 1 scalar (carry formulation, stepping;
+                    # above 32 frames the device picks between stepping and locating the wraps: DESIGN 3.2b)
+                    "formulation": ("carry (stepping / wrap events, picked on the device)" if frames > 32 else "carry (stepping)")
+                                   if frames > 16 and voices * frames >= 1 << 31 else "direct",
                     "int_valu_frac": round(vs * (1.5 if frames > 16 and voices * frames >= 1 << 31 else 2.5)
                                            / 1e12 / INT_VALU_PEAK_TOPS, 4),
                     "max_voices_48k": int(vs / 48000)})
