@@ -178,8 +178,8 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
                     # vector ops per voice-sample: 2.5 (direct) / 1.5 + 1 scalar (carry formulation, stepping;
                     # above 32 frames the device picks between stepping and locating the wraps: DESIGN 3.2b)
                     "formulation": ("carry (stepping / wrap events, picked on the device)" if frames > 32 else "carry (stepping)")
-                                   if frames > 16 and voices * frames >= 1 << 31 else "direct",
-                    "int_valu_frac": round(vs * (1.5 if frames > 16 and voices * frames >= 1 << 31 else 2.5)
+                                   if frames > 16 and voices * frames >= 1 << 30 else "direct",
+                    "int_valu_frac": round(vs * (1.5 if frames > 16 and voices * frames >= 1 << 30 else 2.5)
                                            / 1e12 / INT_VALU_PEAK_TOPS, 4),
                     "max_voices_48k": int(vs / 48000)})
     # BASELINE config 2: 65 536 voices, 64-frame blocks

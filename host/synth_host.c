@@ -16,6 +16,7 @@
  *
  *   synth.dynamic.host.elf                       real JACK, 64-voice drop-in path
  *   SYNTH_VOICES=1048576 synth.dynamic.host.elf  real JACK, N-voice bank path
+ *   SYNTH_FILL=1                                  the bank starts with every voice sounding
  *   SYNTH_PIPELINE=1 ...                         bank path returns block k-1 while k computes
  *   SYNTH_FAKE_PERIOD_US=1333 ... --fake-jack    pace the scripted callbacks like a sound card
  *   synth.dynamic.host.elf --fake-jack NBLOCKS NFRAMES EVENTS.bin OUT.f32
@@ -79,6 +80,20 @@ static int fake_midi_event_get(jack_midi_event_t *e, void *b, uint32_t i) { (voi
 /* ---- SYNTH: either the reference's struct synth or an N-voice bank --------- */
 static struct synth synth;               /* linux/synth.c:208 */
 static smx_bank *bank;                   /* SYNTH_VOICES > 64 */
+
+/* SYNTH_FILL=1: start with every voice of the bank sounding (notes 21..108 spread over the voices,
+ * scattered phases) instead of silence -- what a latency measurement of a full bank needs. */
+static void bank_fill(smx_bank *b, uint32_t n) {
+    uint32_t *inc = malloc((size_t)n * 4), *st = malloc((size_t)n * 4);
+    ASSERT(inc && st);
+    for (uint32_t v = 0; v < n; v++) {
+        uint32_t h = v * 2654435761u;
+        inc[v] = note_to_inc(21 + (int)((h >> 12) % 88u));
+        st[v] = h * 40503u + 12345u;
+    }
+    ASSERT(0 == smx_bank_load(b, inc, st));
+    free(inc); free(st);
+}
 static jack_port_t *midi_in, *audio_out; /* linux/synth.c:214-221 */
 
 static inline void process_midi(jack_nframes_t nframes) {        /* linux/synth.c:227-260 */
@@ -158,6 +173,7 @@ int main(int argc, char **argv) {
         audio_out = FAKE_AUDIO_PORT;
         if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
         if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
+        if (bank && getenv("SYNTH_FILL")) bank_fill(bank, (uint32_t)voices);
         synth_init(&synth);
         FILE *out = fopen(argv[5], "wb");
         ASSERT(out);
@@ -205,6 +221,7 @@ int main(int argc, char **argv) {
         ASSERT(audio_out = jack.port_register(client, "audio_out", JACK_DEFAULT_AUDIO_TYPE, JackPortIsOutput, 0));
         if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
         if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
+        if (bank && getenv("SYNTH_FILL")) bank_fill(bank, (uint32_t)voices);
         synth_init(&synth);
         jack.set_process_callback(client, process, 0);
         ASSERT(!mlockall(MCL_CURRENT | MCL_FUTURE));

@@ -26,7 +26,7 @@
 //    event rebases one voice: state0 += T*(inc_old - inc_new) (saw_rebase_kernel), which
 //    keeps state0 + T*inc continuous -- the reference's "note_on does not reset the phase".
 //
-// Long blocks of big banks (> 16 frames, >= 2^31 voice-samples) take a second formulation
+// Long blocks of big banks (> 16 frames, >= 2^30 voice-samples) take a second formulation
 // (saw_bank_carry_kernel) that needs 2 instead of 2.5 vector ops per voice-sample:
 // with u = state ^ 0x80000000 (offset binary) the arithmetic shift becomes a logical
 // one, (int)state >> 4 == (u >> 4) - 2^27, and because every term is a floor,
@@ -704,8 +704,11 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     }
     static const bool no_carry = getenv("SMX_SAW_NO_CARRY") != nullptr;      // A/B switch
     // measured crossover on MI355X: the carry formulation's fixed cost (histogram fold, slot
-    // atomics, second kernel) pays off from about 2^31 voice-samples per launch
-    const bool big = (unsigned long long)n_pad * nframes >= (1ull << 31);
+    // atomics, further kernels) pays off from about 2^30 voice-samples per launch (16 Mi voices x
+    // 64 frames: direct 78 us, stepping 77 us, wrap events 69 us; 8 Mi voices: 48 / 52 / 49 us)
+    static const char *cm = getenv("SMX_SAW_CARRY_MIN_LOG2");           // tuning override
+    static const unsigned carry_min_log2 = cm ? (unsigned)atoi(cm) : 30u;
+    const bool big = (unsigned long long)n_pad * nframes >= (1ull << carry_min_log2);
     if (nframes > 16 && n_pad >= (1u << 20) && big && d_scratch && !no_carry) {
         // carry-count formulation: 2 vector ops per voice-sample
         const uint32_t ngroups = n_pad / 4;

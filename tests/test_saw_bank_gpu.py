@@ -190,7 +190,7 @@ def test_carry_formulation_blocks(smx, orc, inc_table, frac):
     """> 32 frames on >= 2^20 voices run the carry-count formulation (saw_bank.hip):
     full and partial chunks, several chunks per launch, mixed with short blocks that take
     the direct formulation on the same bank."""
-    n = (1 << 25) + 1000          # n * frames >= 2^31 selects the carry formulation for >= 64 frames
+    n = (1 << 25) + 1000          # n * frames >= 2^30 selects the carry formulation for >= 64 frames
     inc, state = synthetic.saw_bank(n, 0x5EED0C00, inc_table, active_fraction=frac)
     _check(smx, orc, inc, state, [64, 1, 65, 16, 100, 32, 17])
 

@@ -2,8 +2,8 @@
 # tools/rt_latency.sh -- wall time of the JACK process() callback (fake-JACK harness) per 64-frame block
 # for growing banks, synchronous and pipelined.  Run on the GPU box from the repo root.
 : > /tmp/ev.bin
-# paced at the JACK operating point (64 frames @ 48 kHz = 1333 us per callback)
+# every voice of the bank sounding (SYNTH_FILL: piano-range notes), paced at the JACK operating point (64 frames @ 48 kHz = 1333 us per callback)
 for v in 64 65536 1048576 16777216 67108864 268435456; do
-  SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync      /"
-  SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v SYNTH_PIPELINE=1 ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/pipelined /"
+  SYNTH_FILL=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync      /"
+  SYNTH_FILL=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v SYNTH_PIPELINE=1 ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/pipelined /"
 done
