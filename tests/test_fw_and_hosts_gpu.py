@@ -110,6 +110,33 @@ def test_synth_host_fake_jack(tmp_path, orc, voices):
     assert np.array_equal(got.view(np.uint32), np.concatenate(want).view(np.uint32))
 
 
+def test_synth_host_sounding_bank(tmp_path, orc):
+    """SYNTH_FILL=1: the host program starts with every voice of the bank sounding (the bank the
+    real-time latency log is measured on); a few note events on top (voice 0 is stolen: the bank is
+    full), output against the oracle."""
+    voices = 3000
+    events = [(2, [0x90, 40, 100]), (5, [0x80, 40, 0]), (6, [0x90, 100, 100])]
+    ev, out = tmp_path / "ev.bin", tmp_path / "out.f32"
+    _events_file(ev, events)
+    env = dict(os.environ, SYNTH_VOICES=str(voices), SYNTH_FILL="1")
+    r = subprocess.run([SYNTH_ELF, "--fake-jack", "12", "64", str(ev), str(out)], env=env,
+                       stdin=subprocess.DEVNULL, capture_output=True, timeout=120)
+    assert r.returncode == 1, r.stderr.decode()
+    got = np.fromfile(out, np.float32)
+    v = np.arange(voices, dtype=np.uint64)
+    h = (v * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    inc = np.array([orc.orc_note_to_inc(21 + int((x >> np.uint64(12)) % np.uint64(88))) for x in h], np.uint32)
+    st = ((h * np.uint64(40503) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    n2v = np.zeros(128, np.int32)
+    want = []
+    for blk in range(12):
+        for b, msg in events:
+            if b == blk:
+                orc.orc_midi_event(n2v, inc, voices, np.array(msg, np.uint8), 3)
+        want.append(oracle.synth_run(orc, inc, st, 64)[1])
+    assert np.array_equal(got.view(np.uint32), np.concatenate(want).view(np.uint32))
+
+
 def test_fw_host_port_protocol(orc):
     """{packet,4} on stdin/stdout like an Erlang port (erl/jack_client.erl:63-68)."""
     p = subprocess.Popen([FW_ELF, "3", "1"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
