@@ -308,7 +308,7 @@ template <bool NT, bool MULTI, int TC, bool EVENTS>
 __global__ __launch_bounds__(256)
 void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
                            SawPartial *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
-                           const uint32_t *__restrict__ mode_flag)
+                           const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
 {
     static_assert(!EVENTS || TC == 64, "the event form is built for 64-frame chunks");
     __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
@@ -318,6 +318,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     __shared__ uint2 EL[EVENTS ? 4 * 256 : 1];     // EVENTS: per wave, the (phase, inc) of the voices that wrap
     if (mode_flag && (*mode_flag != 0u) != EVENTS) return;     // the other form runs this launch
     const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (ran_long && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ran_long = 0;   // 64-frame slot layout
     const uint32_t t0 = tbase + (MULTI ? blockIdx.y * 64u : 0u);   // phase offset of this chunk
     for (uint32_t i = tid; i < 64 * 65; i += 256) (&M[0][0])[i] = 0;
     H[tid] = 0;
@@ -480,14 +481,203 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicAdd(&out->I, S[1]); atomicMax(&out->maxinc, MX); }
 }
 
+// The event form for launches of 256 frames and more: 256-frame chunks, so that the divisions are
+// paid once per 256 frames.  The wraps go to ONE histogram per workgroup (a per-lane matrix of 256
+// frames would not fit), the nibble histogram travels to the slot as it is, and the finalize
+// kernel does the rest.  Slot layout of a 256-frame chunk:
+struct SawPartialL {
+    unsigned long long U0, I;     // sum u_v(t0), sum inc_v
+    uint32_t maxinc, pad_;
+    uint32_t H[256];              // voices per (phase & 15, inc & 15) class
+    uint32_t W[256];              // wraps at frame t (t -> t+1)
+};
+constexpr uint32_t SAW_LONG = 256;
+
+template <bool NT>
+__global__ __launch_bounds__(256)
+void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
+                                SawPartialL *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
+                                const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
+{
+    __shared__ uint32_t hist[SAW_LONG];
+    __shared__ uint32_t H[256];
+    __shared__ unsigned long long S[2];
+    __shared__ uint32_t MX;
+    __shared__ uint2 EL[4 * 256];
+    if (mode_flag && *mode_flag == 0u) return;                 // the stepping form runs this launch
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ran_long = 1;    // 256-frame slot layout
+    const uint32_t t0 = tbase + blockIdx.y * SAW_LONG;
+    hist[tid] = 0;
+    H[tid] = 0;
+    if (tid < 2) S[tid] = 0;
+    if (tid == 0) MX = 0;
+    __syncthreads();
+
+    unsigned long long sumU = 0, sumI = 0;
+    uint32_t mx = 0;
+    const uint32_t nrows = ngroups >> 8;
+    const u32x4 *inc4 = reinterpret_cast<const u32x4 *>(inc);
+    const u32x4 *st4 = reinterpret_cast<const u32x4 *>(st_in);
+    u32x4 a_next = 0, b_next = 0;
+    if (blockIdx.x < nrows) {
+        a_next = stream_load<NT>(inc4 + blockIdx.x * 256u + tid);
+        b_next = stream_load<NT>(st4 + blockIdx.x * 256u + tid);
+    }
+    uint2 *list = &EL[(tid >> 6) * 256];
+    for (uint32_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const u32x4 a = a_next, b = b_next;
+        const uint32_t rn = min(row + gridDim.x, nrows - 1) * 256u + tid;
+        a_next = stream_load<NT>(inc4 + rn);
+        b_next = stream_load<NT>(st4 + rn);
+        const uint32_t vi[4] = {a.x, a.y, a.z, a.w};
+        uint32_t vu[4];
+        vu[0] = (a.x ? b.x + t0 * a.x : 0u) ^ 0x80000000u;
+        vu[1] = (a.y ? b.y + t0 * a.y : 0u) ^ 0x80000000u;
+        vu[2] = (a.z ? b.z + t0 * a.z : 0u) ^ 0x80000000u;
+        vu[3] = (a.w ? b.w + t0 * a.w : 0u) ^ 0x80000000u;
+        sumU += (unsigned long long)vu[0] + vu[1] + vu[2] + vu[3];
+        sumI += (unsigned long long)a.x + a.y + a.z + a.w;
+        mx = max(max(mx, a.x), max(max(a.y, a.z), a.w));
+        uint32_t nw = 0;                                      // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(&H[((vu[k] & 15) << 4) | (vi[k] & 15)], 1u);
+            // wraps within 256 frames?  u + 256*inc >= 2^32
+            const bool w = (vi[k] >> 24) != 0u || vu[k] + (vi[k] << 8) < vu[k];
+            const unsigned long long m = __ballot(w);
+            const uint32_t pos = nw + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (w) list[pos] = make_uint2(vu[k], vi[k]);
+            nw += (uint32_t)__builtin_popcountll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t ei[4], et[4], er[4], eq[4], erm[4], ee[4];
+        bool more = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            et[k] = 0xFFFFFFFFu; ei[k] = er[k] = eq[k] = erm[k] = ee[k] = 0;
+            if (64u * k < nw) {                               // wave-uniform
+                const uint32_t e = lane + 64u * k;
+                const uint2 en = list[e < nw ? e : 0u];
+                const uint32_t d = en.y;
+                const uint32_t n1 = ~en.x / d;
+                eq[k] = 0xFFFFFFFFu / d;
+                erm[k] = 0xFFFFFFFFu - eq[k] * d;
+                ee[k] = d - 1u - erm[k];
+                eq[k] = min(eq[k], 1u << 30);
+                er[k] = en.x + (n1 + 1u) * d;
+                ei[k] = d;
+                if (e < nw) et[k] = n1;
+                more |= et[k] < SAW_LONG;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // every gap is at least one frame: SAW_LONG rounds always suffice
+        for (uint32_t round = 0; round < SAW_LONG && __any(more); round++) {
+            more = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (et[k] < SAW_LONG) {
+                    atomicAdd(&hist[et[k]], 1u);
+                    const bool c = er[k] <= erm[k];
+                    et[k] += eq[k] + (c ? 1u : 0u);
+                    er[k] += c ? ee[k] : ee[k] - ei[k];
+                    more |= et[k] < SAW_LONG;
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sumU += __shfl_xor(sumU, o);
+        sumI += __shfl_xor(sumI, o);
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    }
+    if (lane == 0) { atomicAdd(&S[0], sumU); atomicAdd(&S[1], sumI); atomicMax(&MX, mx); }
+    __syncthreads();
+    SawPartialL *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
+    if (hist[tid]) atomicAdd(&out->W[tid], hist[tid]);
+    if (H[tid]) atomicAdd(&out->H[tid], H[tid]);
+    if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicAdd(&out->I, S[1]); atomicMax(&out->maxinc, MX); }
+}
+
+// Finalize of a 256-frame chunk of the long event form (called from saw_bank_finalize_kernel).
+__device__ __forceinline__ void saw_finalize_long(SawPartialL *__restrict__ partial, int32_t *__restrict__ bus,
+                                                  int32_t *__restrict__ bus_next, uint32_t nframes,
+                                                  uint32_t nvoices, uint32_t *__restrict__ mode_flag)
+{
+    __shared__ uint32_t Hs[256], Wsum[4];
+    __shared__ unsigned long long US[2];
+    __shared__ uint32_t MXs;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SawPartialL *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
+    uint32_t w = 0, h = 0;
+    for (int k0 = 0; k0 < SAW_SLOTS; k0 += 16) {
+        uint32_t wv[16], hv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { wv[k] = p[k0 + k].W[tid]; hv[k] = p[k0 + k].H[tid]; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { w += wv[k]; h += hv[k]; p[k0 + k].W[tid] = 0; p[k0 + k].H[tid] = 0; }
+    }
+    Hs[tid] = h;
+    if (wave == 0) {                                          // lane s folds slot s's scalars
+        unsigned long long u0 = p[lane].U0, ii = p[lane].I;
+        uint32_t m = p[lane].maxinc;
+        p[lane].U0 = 0; p[lane].I = 0; p[lane].maxinc = 0;
+        for (int o = 32; o > 0; o >>= 1) {
+            u0 += __shfl_xor(u0, o);
+            ii += __shfl_xor(ii, o);
+            m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        }
+        if (lane == 0) { US[0] = u0; US[1] = ii; MXs = m; }
+    }
+    // exclusive prefix of the wraps over the 256 frames: wave scan + the waves' totals
+    uint32_t incl = w;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += up;
+    }
+    if (lane == 63) Wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wraps = incl - w;
+    for (uint32_t k = 0; k < wave; k++) wraps += Wsum[k];
+    // low-nibble sum at frame t: the classes (lo, li) contribute ((lo + t*li) & 15) each
+    const uint32_t t = tid;
+    unsigned long long L = 0;
+#pragma unroll 8
+    for (uint32_t bin = 0; bin < 256; bin++)
+        L += (unsigned long long)Hs[bin] * (((bin >> 4) + t * (bin & 15)) & 15);
+    const unsigned long long U0 = US[0], I = US[1];
+    const unsigned long long x = U0 + (unsigned long long)t * I - ((unsigned long long)(wraps & 15u) << 32) - L;
+    const uint32_t r = (uint32_t)(x >> 4) - (nvoices << 27);
+    const uint32_t f = blockIdx.x * SAW_LONG + t;
+    if (f < nframes) {
+        bus[f] = (int32_t)r;
+        bus_next[f] = 0;
+    }
+    if (blockIdx.x == 0 && tid == 0 && mode_flag)
+        *mode_flag = (MXs < (13u << 25) && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
+}
+
 // One workgroup per 64-frame chunk: add the chunk's slots (and clear them for the next
 // launch) and emit
 //   bus[t0+t] = ((U0 + t*I - 2^32*W(t) - L(t)) >> 4) - nvoices * 2^27        (mod 2^32)
 __global__ __launch_bounds__(256)
 void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
                               int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
-                              uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag)
+                              uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag,
+                              const uint32_t *__restrict__ ran_long)
 {
+    // which slot layout did this launch fill?  (written by the main kernel that ran, stable here)
+    if (ran_long && *ran_long != 0u) {
+        if (blockIdx.x * SAW_LONG < nframes)
+            saw_finalize_long(reinterpret_cast<SawPartialL *>(partial), bus, bus_next, nframes, nvoices, mode_flag);
+        return;
+    }
+    if (blockIdx.x * 64u >= nframes) return;
     __shared__ unsigned long long Ls[4][64], Us[4][2];
     __shared__ uint32_t Ws[4][64], Mx[4];
     const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
@@ -732,11 +922,31 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             // (64 Mi voices: 64 frames 198 us with 2048, 189 with 4096; 1024 frames 2.68 / 2.56 ms with 4096 / 8192)
             uint32_t gx_ev = ((cg ? (uint32_t)atoi(cg) : (gy == 1 ? 4096u : 8192u)) + gy - 1) / gy;
             if (gx_ev > (ngroups + 255) / 256) gx_ev = (ngroups + 255) / 256;
+            uint32_t *ran_long = flag + 1;                    // which slot layout the launch filled
 #define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_, EV_, FLAG_)                                                   \
     hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, EV_>), dim3((EV_) ? gx_ev : gx, gy),    \
-                       dim3(256), 0, stream, d_inc, d_state_in, part, ngroups, tbase, FLAG_)
+                       dim3(256), 0, stream, d_inc, d_state_in, part, ngroups, tbase, FLAG_, ran_long)
             const bool nt = n_pad >= (1u << 24);
-            if (nframes > 32) {
+            static const bool no_long = getenv("SMX_SAW_NO_LONG_EVENTS") != nullptr;          // A/B switch
+            if (nframes >= SAW_LONG && !no_long) {
+                // long launches: the stepping form in 64-frame chunks and the event form in 256-frame
+                // chunks (divisions paid once per 256 frames) are queued, the flag picks one; the
+                // finalize kernel reads from `ran_long` which slot layout was filled
+                const uint32_t gyl = (nframes + SAW_LONG - 1) / SAW_LONG;
+                const uint32_t *f = (no_events || force_events) ? nullptr : flag;
+                if (!force_events) {
+                    if (nt) SMX_CARRY_LAUNCH(true, true, 64, false, f); else SMX_CARRY_LAUNCH(false, true, 64, false, f);
+                }
+                if (!no_events) {
+                    uint32_t gxl = ((cg ? (uint32_t)atoi(cg) : 8192u) + gyl - 1) / gyl;
+                    if (gxl > (ngroups + 255) / 256) gxl = (ngroups + 255) / 256;
+                    auto *partl = reinterpret_cast<SawPartialL *>(part);
+                    if (nt) hipLaunchKernelGGL(saw_bank_event_long_kernel<true>, dim3(gxl, gyl), dim3(256), 0, stream,
+                                               d_inc, d_state_in, partl, ngroups, tbase, f, ran_long);
+                    else    hipLaunchKernelGGL(saw_bank_event_long_kernel<false>, dim3(gxl, gyl), dim3(256), 0, stream,
+                                               d_inc, d_state_in, partl, ngroups, tbase, f, ran_long);
+                }
+            } else if (nframes > 32) {
                 // 64-frame chunks: both forms are queued, the device-side flag picks one (the other
                 // returns at once); the finalize kernel refreshes the flag from this launch's statistics
                 const uint32_t *f = (no_events || force_events) ? nullptr : flag;
@@ -753,7 +963,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             }
 #undef SMX_CARRY_LAUNCH
             hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
-                               d_bus_next, nframes, n_pad, flag);
+                               d_bus_next, nframes, n_pad, flag, ran_long);
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         }

@@ -209,40 +209,47 @@ def test_carry_formulation_extreme_increments(smx, orc):
     _check(smx, orc, np.ascontiguousarray(inc[:m]), np.ascontiguousarray(state[:m]), [600, 513])
 
 
+def _adversarial_increments(n):
+    k = np.arange(n, dtype=np.uint64)
+    return np.where(k % 5 == 0, 0xFFFFFFFF, np.where(k % 5 == 1, 1, np.where(k % 5 == 2, 0x80000000,
+                    np.where(k % 5 == 3, 0, (k * 2654435761) & 0xFFFFFFFF)))).astype(np.uint32)
+
+
 @pytest.mark.parametrize("form", [1, 2, 0])       # SMX_FORM_STEPPING, SMX_FORM_EVENTS, SMX_FORM_AUTO
 def test_long_block_forms_agree(smx, orc, inc_table, form):
     """smx_bank_set_block_form: stepping, wrap events and the device-side automatic choice give the
     oracle's bits on a piano-range bank (where AUTO switches to events after its first long block),
     on arbitrary 32-bit increments (many wraps per voice: the event loop runs long, the result must
     not care), on all-wrap / never-wrap / half-scale increments, with voices off, over single
-    chunks, partial chunks and multi-chunk launches, and across a reload of the increments."""
-    n = (1 << 25) + 2048
-    inc, state = synthetic.saw_bank(n, 0x5EED0E0E, inc_table, active_fraction=0.9)
-    bank = smx.SawBank(n)
-    bank.set_block_form(form)
-    bank.load(inc, state)
-    st = state.copy()
+    chunks, partial chunks and multi-chunk launches, and across a reload of the increments.
+    A 2^25-voice bank for blocks up to 200 frames (64-frame chunks), a 2^22-voice bank for 256
+    frames and more (256-frame chunks in the event form)."""
+    for n, piano_blocks, hard_blocks in (((1 << 25) + 2048, [64, 64, 130, 33, 64, 1, 200], [64, 64, 100]),
+                                         ((1 << 22) + 1024, [256, 256, 300, 64, 513, 1000], [256, 257, 600])):
+        inc, state = synthetic.saw_bank(n, 0x5EED0E0E, inc_table, active_fraction=0.9)
+        bank = smx.SawBank(n)
+        bank.set_block_form(form)
+        bank.load(inc, state)
+        st = state.copy()
 
-    def blocks(frames_list):
-        for nf in frames_list:
-            bus, _ = bank.run(nf)
-            obus, _ = oracle.synth_run(orc, inc, st, nf)
-            assert np.array_equal(bus, obus), "form=%d frames=%d" % (form, nf)
+        def blocks(frames_list):
+            for nf in frames_list:
+                bus, _ = bank.run(nf)
+                obus, _ = oracle.synth_run(orc, inc, st, nf)
+                assert np.array_equal(bus, obus), "form=%d n=%d frames=%d" % (form, n, nf)
 
-    blocks([64, 64, 130, 33, 64, 1, 200])
-    assert np.array_equal(bank.read()[1], st)
-    k = np.arange(n, dtype=np.uint64)
-    inc = np.where(k % 5 == 0, 0xFFFFFFFF, np.where(k % 5 == 1, 1, np.where(k % 5 == 2, 0x80000000,
-                   np.where(k % 5 == 3, 0, (k * 2654435761) & 0xFFFFFFFF)))).astype(np.uint32)
-    bank.load(inc=inc)                                     # resets the statistic: stepping first under AUTO
-    blocks([64, 64, 100])
-    inc = synthetic.saw_bank(n, 0x5EED0E0F, inc_table, active_fraction=1.0)[0]
-    bank.load(inc=inc)
-    blocks([64, 64, 64])
-    ginc, gst = bank.read()
-    assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
-    assert smx.lib().smx_bank_set_block_form(bank._h, 3) == -1
-    bank.close()
+        blocks(piano_blocks)
+        assert np.array_equal(bank.read()[1], st)
+        inc = _adversarial_increments(n)
+        bank.load(inc=inc)                                 # resets the statistic: stepping first under AUTO
+        blocks(hard_blocks)
+        inc = synthetic.saw_bank(n, 0x5EED0E0F, inc_table, active_fraction=1.0)[0]
+        bank.load(inc=inc)
+        blocks(piano_blocks[:3])
+        ginc, gst = bank.read()
+        assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+        assert smx.lib().smx_bank_set_block_form(bank._h, 3) == -1
+        bank.close()
 
 
 def test_midi_event_bursts_without_sync(smx, orc):
