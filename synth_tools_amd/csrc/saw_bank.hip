@@ -40,6 +40,14 @@
 // the vector unit).  Everything is reduced in integers, so the result is the same
 // bits as the reference loop; a small second kernel combines the per-workgroup
 // partial sums into the int32 bus.
+//
+// W(t) is the ONLY per-sample non-linearity, and it can also be had without stepping: the wraps
+// of a voice lie at frame floor(~u/inc) and then every floor((2^32-1)/inc) or one more frames.
+// The EVENTS form of the carry kernel (64-frame chunks) and saw_bank_event_long_kernel (256-frame
+// chunks, launches of 256 frames and more) locate them and add them to a histogram -- work per
+// WRAP instead of per sample, 1.1 wraps per voice per 64 frames on a piano-range bank.  Which
+// form runs is decided per launch ON THE DEVICE from the bank's own increment statistics (both
+// are queued, one returns at once); both are exact on any bank.
 #include "smx_common.h"
 
 namespace {
