@@ -366,6 +366,44 @@ def test_randomised_block_sequences(smx, orc, inc_table):
         bank.close()
 
 
+def test_randomised_long_blocks_big_banks(smx, orc, inc_table):
+    """Seeded fuzz over the long-block forms (the sizes of test_randomised_block_sequences stay below
+    2^30 voice-samples per launch): banks of 2^22 and 2^24 voices, random block lengths on both sides
+    of the 64- and 256-frame chunk sizes, a random form per trial, reloads between piano-range and
+    arbitrary increments, voices switched off in between, short blocks mixed in."""
+    import os
+    seed = int(os.environ.get("SMX_FUZZ_SEED", "0xB16"), 0)
+    rng = np.random.default_rng(seed)
+    for trial in range(4 * int(os.environ.get("SMX_FUZZ_ROUNDS", "1"))):
+        big = trial % 2 == 1
+        n = ((1 << 24) + 2048) if big else ((1 << 22) + 1024)
+        lengths = [33, 63, 64, 65, 127, 128, 200, 255, 256, 300] if big else [256, 257, 300, 511, 512, 513, 700]
+        inc, state = synthetic.saw_bank(n, 0xB160 + trial + seed, inc_table, active_fraction=float(rng.choice([0.5, 1.0])))
+        bank = smx.SawBank(n)
+        bank.set_block_form(int(rng.integers(0, 3)))
+        bank.load(inc, state)
+        st = state.copy()
+        inc = inc.copy()
+        for _ in range(5):
+            r = rng.random()
+            if r < 0.25:                                       # arbitrary increments
+                inc = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+                inc[rng.random(n) < 0.3] = 0
+                bank.load(inc=inc)
+            elif r < 0.5:                                      # back to a piano-range bank
+                inc = synthetic.saw_bank(n, int(rng.integers(1, 1 << 30)), inc_table)[0]
+                bank.load(inc=inc)
+            elif r < 0.6:
+                bank.set_block_form(int(rng.integers(0, 3)))
+            nf = int(rng.choice(lengths)) if rng.random() < 0.8 else int(rng.choice([1, 7, 16, 32]))
+            bus, _ = bank.run(nf)
+            obus, _ = oracle.synth_run(orc, inc, st, nf)
+            assert np.array_equal(bus, obus), "trial=%d n=%d nf=%d" % (trial, n, nf)
+        ginc, gst = bank.read()
+        assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+        bank.close()
+
+
 def test_pipelined_block_mode(smx, orc, inc_table):
     """SMX_BLOCK_PIPELINED: smx_bank_run returns the previous block (silence first), state and
     note events behave as in sync mode; switching back to sync returns current blocks."""
