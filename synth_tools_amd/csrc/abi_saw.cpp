@@ -159,7 +159,7 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
     SMX_HIP(hipHostMalloc((void **)&b->h_bus, (size_t)cap * 4, hipHostMallocDefault));
     if (b->d_scratch) SMX_HIP(hipFree(b->d_scratch));
     b->d_scratch = nullptr;
-    if (b->n_pad >= (1u << 20)) {
+    if (b->n_pad >= (1u << 16)) {
         SMX_HIP(hipMalloc(&b->d_scratch, smx::saw_scratch_bytes(cap)));
         SMX_HIP(hipMemset(b->d_scratch, 0, smx::saw_scratch_bytes(cap)));   // slots are kept zero between launches
     }

@@ -315,6 +315,11 @@ def test_long_blocks_grow_the_bus(smx, orc, inc_table):
     n = 1 << 20
     inc, state = synthetic.saw_bank(n, 0x5EED0B06, inc_table)
     _check(smx, orc, inc, state, [64, 4500, 64])          # 4500 frames x 2^20 voices: carry path, 71 chunks
+    # long launches of smaller banks (from 2^16 voices) reach 2^30 voice-samples too: stepping on the
+    # first one, 256-frame event chunks afterwards, short blocks (direct formulation) in between
+    for n, frames in (((1 << 18) + 1024, [4096, 64, 4100, 5000]), (1 << 16, [16384, 16390])):
+        inc, state = synthetic.saw_bank(n, 0x5EED0B07 + n, inc_table, active_fraction=0.9)
+        _check(smx, orc, inc, state, frames)
 
 
 def test_randomised_block_sequences(smx, orc, inc_table):
