@@ -182,6 +182,14 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
                     "int_valu_frac": round(vs * (1.5 if frames > 16 and voices * frames >= 1 << 30 else 2.5)
                                            / 1e12 / INT_VALU_PEAK_TOPS, 4),
                     "max_voices_48k": int(vs / 48000)})
+    # the same 64-frame blocks on a bank of high voices only (MIDI notes 100..127: 3..17 wraps per voice
+    # per block): the device-side statistic keeps the stepping form, whose time does not depend on the data
+    r = synthetic.splitmix64(0x5EED0009, voices)
+    hi_inc = np.ascontiguousarray(tab[100 + (r % np.uint64(28)).astype(np.int64)].astype(np.uint32))
+    big_bank.load(inc=hi_inc)
+    ms = time_saw(sta, big_bank, 64, 50, 5)
+    out.append({"workload": "saw bank, %d voices, 64 frames/step, notes 100..127 only (stepping form picked on the device)" % voices,
+                "value": round(voices * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5)})
     # BASELINE config 2: 65 536 voices, 64-frame blocks
     inc, st = synthetic.saw_bank(65536, 0x5EED0002, tab)
     b = sta.SawBank(65536)
