@@ -512,6 +512,7 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
     __shared__ unsigned long long S[2];
     __shared__ uint32_t MX;
     __shared__ uint2 EL[4 * 256];
+    __shared__ uint32_t CNT[4 * 16];
     if (mode_flag && *mode_flag == 0u) return;                 // the stepping form runs this launch
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ran_long = 1;    // 256-frame slot layout
@@ -547,56 +548,69 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
         sumU += (unsigned long long)vu[0] + vu[1] + vu[2] + vu[3];
         sumI += (unsigned long long)a.x + a.y + a.z + a.w;
         mx = max(max(mx, a.x), max(max(a.y, a.z), a.w));
-        uint32_t nw = 0;                                      // wave-uniform
+        // (1) The wave sorts its wrapping voices by the binary order of their wrap count K (a counting
+        //     sort over 9 classes in LDS): dealt out lane by lane afterwards, slot k of every lane then
+        //     holds voices of about the same K, and the slots are worked off one after the other -- a
+        //     slot's loop runs as long as ITS busiest voice, not as long as the wave's.
+        uint32_t *cnt = &CNT[(tid >> 6) * 16];
+        if (lane < 16) cnt[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t cls[4], pos[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             atomicAdd(&H[((vu[k] & 15) << 4) | (vi[k] & 15)], 1u);
-            // wraps within 256 frames?  u + 256*inc >= 2^32
-            const bool w = (vi[k] >> 24) != 0u || vu[k] + (vi[k] << 8) < vu[k];
-            const unsigned long long m = __ballot(w);
-            const uint32_t pos = nw + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (w) list[pos] = make_uint2(vu[k], vi[k]);
-            nw += (uint32_t)__builtin_popcountll(m);
+            // wraps within 256 frames: K = (u + 256*inc) >> 32
+            const uint32_t lo = vu[k] + (vi[k] << 8);
+            const uint32_t K = (vi[k] >> 24) + (lo < vu[k] ? 1u : 0u);
+            cls[k] = K ? 31u - (uint32_t)__builtin_clz(K) : 0xFFFFFFFFu;       // 0..8, or none
+            pos[k] = 0;
+            if (K) pos[k] = atomicAdd(&cnt[cls[k]], 1u);                       // place within the class
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t ei[4], et[4], er[4], eq[4], erm[4], ee[4];
-        bool more = false;
+        // exclusive prefix over the classes (lanes 0..15), total = number of wrapping voices
+        uint32_t c = lane < 16 ? cnt[lane] : 0u;
+        uint32_t incl = c;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            et[k] = 0xFFFFFFFFu; ei[k] = er[k] = eq[k] = erm[k] = ee[k] = 0;
-            if (64u * k < nw) {                               // wave-uniform
-                const uint32_t e = lane + 64u * k;
-                const uint2 en = list[e < nw ? e : 0u];
-                const uint32_t d = en.y;
-                const uint32_t n1 = ~en.x / d;
-                eq[k] = 0xFFFFFFFFu / d;
-                erm[k] = 0xFFFFFFFFu - eq[k] * d;
-                ee[k] = d - 1u - erm[k];
-                eq[k] = min(eq[k], 1u << 30);
-                er[k] = en.x + (n1 + 1u) * d;
-                ei[k] = d;
-                if (e < nw) et[k] = n1;
-                more |= et[k] < SAW_LONG;
-            }
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += up;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const uint32_t nw = __shfl(incl, 15);                 // wave-uniform
         __builtin_amdgcn_wave_barrier();
-        // every gap is at least one frame: SAW_LONG rounds always suffice
-        for (uint32_t round = 0; round < SAW_LONG && __any(more); round++) {
-            more = false;
+        if (lane < 16) cnt[lane] = incl - c;                   // class bases
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (et[k] < SAW_LONG) {
-                    atomicAdd(&hist[et[k]], 1u);
-                    const bool c = er[k] <= erm[k];
-                    et[k] += eq[k] + (c ? 1u : 0u);
-                    er[k] += c ? ee[k] : ee[k] - ei[k];
-                    more |= et[k] < SAW_LONG;
+        for (int k = 0; k < 4; k++)
+            if (cls[k] != 0xFFFFFFFFu) list[cnt[cls[k]] + pos[k]] = make_uint2(vu[k], vi[k]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // (2) slot by slot: entry lane + 64*k, its two divisions, its wraps
+        for (uint32_t k = 0; 64u * k < nw; k++) {              // wave-uniform trip count
+            const uint32_t e = lane + 64u * k;
+            const uint2 en = list[e < nw ? e : 0u];
+            const uint32_t d = en.y;
+            const uint32_t n1 = ~en.x / d;
+            uint32_t eq = 0xFFFFFFFFu / d;
+            const uint32_t erm = 0xFFFFFFFFu - eq * d;
+            const uint32_t ee = d - 1u - erm;
+            eq = min(eq, 1u << 30);                           // keeps et + gap from wrapping (inc == 1)
+            uint32_t er = en.x + (n1 + 1u) * d;               // the phase right after the first wrap
+            uint32_t et = e < nw ? n1 : 0xFFFFFFFFu;
+            // every gap is at least one frame: SAW_LONG rounds always suffice
+            for (uint32_t round = 0; round < SAW_LONG && __any(et < SAW_LONG); round++) {
+                if (et < SAW_LONG) {
+                    atomicAdd(&hist[et], 1u);
+                    const bool cc = er <= erm;
+                    et += eq + (cc ? 1u : 0u);
+                    er += cc ? ee : ee - d;
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // list and counters are free for the next row
+        __builtin_amdgcn_wave_barrier();
     }
     for (int o = 32; o > 0; o >>= 1) {
         sumU += __shfl_xor(sumU, o);
