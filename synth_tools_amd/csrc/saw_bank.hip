@@ -493,21 +493,25 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
 // paid once per 256 frames.  The wraps go to ONE histogram per workgroup (a per-lane matrix of 256
 // frames would not fit), the nibble histogram travels to the slot as it is, and the finalize
 // kernel does the rest.  Slot layout of a 256-frame chunk:
+// (TL = 256; launches of 1024 frames and more use 1024-frame chunks, TL = 1024.)
+template <uint32_t TL>
 struct SawPartialL {
     unsigned long long U0, I;     // sum u_v(t0), sum inc_v
     uint32_t maxinc, pad_;
     uint32_t H[256];              // voices per (phase & 15, inc & 15) class
-    uint32_t W[256];              // wraps at frame t (t -> t+1)
+    uint32_t W[TL];               // wraps at frame t (t -> t+1)
 };
-constexpr uint32_t SAW_LONG = 256;
+constexpr uint32_t SAW_LONG = 256;         // shortest launch that takes the long event form
 
-template <bool NT>
+template <bool NT, uint32_t TL>
 __global__ __launch_bounds__(256)
 void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
-                                SawPartialL *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
+                                SawPartialL<TL> *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
                                 const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
 {
-    __shared__ uint32_t hist[SAW_LONG];
+    static_assert(TL == 256 || TL == 1024, "chunk lengths of the long event form");
+    constexpr uint32_t LG = TL == 256 ? 8 : 10;
+    __shared__ uint32_t hist[TL];
     __shared__ uint32_t H[256];
     __shared__ unsigned long long S[2];
     __shared__ uint32_t MX;
@@ -515,9 +519,9 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
     __shared__ uint32_t CNT[4 * 16];
     if (mode_flag && *mode_flag == 0u) return;                 // the stepping form runs this launch
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ran_long = 1;    // 256-frame slot layout
-    const uint32_t t0 = tbase + blockIdx.y * SAW_LONG;
-    hist[tid] = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ran_long = TL == 256 ? 1u : 2u;   // slot layout of this launch
+    const uint32_t t0 = tbase + blockIdx.y * TL;
+    for (uint32_t i = tid; i < TL; i += 256) hist[i] = 0;
     H[tid] = 0;
     if (tid < 2) S[tid] = 0;
     if (tid == 0) MX = 0;
@@ -560,10 +564,10 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             atomicAdd(&H[((vu[k] & 15) << 4) | (vi[k] & 15)], 1u);
-            // wraps within 256 frames: K = (u + 256*inc) >> 32
-            const uint32_t lo = vu[k] + (vi[k] << 8);
-            const uint32_t K = (vi[k] >> 24) + (lo < vu[k] ? 1u : 0u);
-            cls[k] = K ? 31u - (uint32_t)__builtin_clz(K) : 0xFFFFFFFFu;       // 0..8, or none
+            // wraps within the chunk: K = (u + TL*inc) >> 32
+            const uint32_t lo = vu[k] + (vi[k] << LG);
+            const uint32_t K = (vi[k] >> (32 - LG)) + (lo < vu[k] ? 1u : 0u);
+            cls[k] = K ? 31u - (uint32_t)__builtin_clz(K) : 0xFFFFFFFFu;       // 0..LG, or none
             pos[k] = 0;
             if (K) pos[k] = atomicAdd(&cnt[cls[k]], 1u);                       // place within the class
         }
@@ -599,9 +603,9 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
             eq = min(eq, 1u << 30);                           // keeps et + gap from wrapping (inc == 1)
             uint32_t er = en.x + (n1 + 1u) * d;               // the phase right after the first wrap
             uint32_t et = e < nw ? n1 : 0xFFFFFFFFu;
-            // every gap is at least one frame: SAW_LONG rounds always suffice
-            for (uint32_t round = 0; round < SAW_LONG && __any(et < SAW_LONG); round++) {
-                if (et < SAW_LONG) {
+            // every gap is at least one frame: TL rounds always suffice
+            for (uint32_t round = 0; round < TL && __any(et < TL); round++) {
+                if (et < TL) {
                     atomicAdd(&hist[et], 1u);
                     const bool cc = er <= erm;
                     et += eq + (cc ? 1u : 0u);
@@ -619,29 +623,44 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
     }
     if (lane == 0) { atomicAdd(&S[0], sumU); atomicAdd(&S[1], sumI); atomicMax(&MX, mx); }
     __syncthreads();
-    SawPartialL *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
-    if (hist[tid]) atomicAdd(&out->W[tid], hist[tid]);
+    SawPartialL<TL> *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
+    for (uint32_t i = tid; i < TL; i += 256)
+        if (hist[i]) atomicAdd(&out->W[i], hist[i]);
     if (H[tid]) atomicAdd(&out->H[tid], H[tid]);
     if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicAdd(&out->I, S[1]); atomicMax(&out->maxinc, MX); }
 }
 
-// Finalize of a 256-frame chunk of the long event form (called from saw_bank_finalize_kernel).
-__device__ __forceinline__ void saw_finalize_long(SawPartialL *__restrict__ partial, int32_t *__restrict__ bus,
+// Finalize of a TL-frame chunk of the long event form (called from saw_bank_finalize_kernel):
+// thread tid owns the frames FPT*tid .. FPT*tid + FPT-1 of the chunk.
+template <uint32_t TL>
+__device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ partial, int32_t *__restrict__ bus,
                                                   int32_t *__restrict__ bus_next, uint32_t nframes,
                                                   uint32_t nvoices, uint32_t *__restrict__ mode_flag)
 {
+    constexpr uint32_t FPT = TL / 256;
     __shared__ uint32_t Hs[256], Wsum[4];
     __shared__ unsigned long long US[2];
     __shared__ uint32_t MXs;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    SawPartialL *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
-    uint32_t w = 0, h = 0;
-    for (int k0 = 0; k0 < SAW_SLOTS; k0 += 16) {
-        uint32_t wv[16], hv[16];
+    SawPartialL<TL> *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
+    uint32_t w[FPT], h = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) { wv[k] = p[k0 + k].W[tid]; hv[k] = p[k0 + k].H[tid]; }
+    for (uint32_t j = 0; j < FPT; j++) w[j] = 0;
+    for (int k0 = 0; k0 < SAW_SLOTS; k0 += 8) {
+        uint32_t wv[8][FPT], hv[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) { w += wv[k]; h += hv[k]; p[k0 + k].W[tid] = 0; p[k0 + k].H[tid] = 0; }
+        for (int k = 0; k < 8; k++) {
+#pragma unroll
+            for (uint32_t j = 0; j < FPT; j++) wv[k][j] = p[k0 + k].W[FPT * tid + j];
+            hv[k] = p[k0 + k].H[tid];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+#pragma unroll
+            for (uint32_t j = 0; j < FPT; j++) { w[j] += wv[k][j]; p[k0 + k].W[FPT * tid + j] = 0; }
+            h += hv[k];
+            p[k0 + k].H[tid] = 0;
+        }
     }
     Hs[tid] = h;
     if (wave == 0) {                                          // lane s folds slot s's scalars
@@ -655,8 +674,11 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL *__restrict__ part
         }
         if (lane == 0) { US[0] = u0; US[1] = ii; MXs = m; }
     }
-    // exclusive prefix of the wraps over the 256 frames: wave scan + the waves' totals
-    uint32_t incl = w;
+    // exclusive prefix of the wraps over the chunk: the thread's own frames, wave scan, waves' totals
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < FPT; j++) mine += w[j];
+    uint32_t incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_up(incl, o);
@@ -664,21 +686,25 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL *__restrict__ part
     }
     if (lane == 63) Wsum[wave] = incl;
     __syncthreads();
-    uint32_t wraps = incl - w;
+    uint32_t wraps = incl - mine;
     for (uint32_t k = 0; k < wave; k++) wraps += Wsum[k];
-    // low-nibble sum at frame t: the classes (lo, li) contribute ((lo + t*li) & 15) each
-    const uint32_t t = tid;
-    unsigned long long L = 0;
-#pragma unroll 8
-    for (uint32_t bin = 0; bin < 256; bin++)
-        L += (unsigned long long)Hs[bin] * (((bin >> 4) + t * (bin & 15)) & 15);
     const unsigned long long U0 = US[0], I = US[1];
-    const unsigned long long x = U0 + (unsigned long long)t * I - ((unsigned long long)(wraps & 15u) << 32) - L;
-    const uint32_t r = (uint32_t)(x >> 4) - (nvoices << 27);
-    const uint32_t f = blockIdx.x * SAW_LONG + t;
-    if (f < nframes) {
-        bus[f] = (int32_t)r;
-        bus_next[f] = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < FPT; j++) {
+        const uint32_t t = FPT * tid + j;
+        // low-nibble sum at frame t: the classes (lo, li) contribute ((lo + t*li) & 15) each
+        unsigned long long L = 0;
+#pragma unroll 8
+        for (uint32_t bin = 0; bin < 256; bin++)
+            L += (unsigned long long)Hs[bin] * (((bin >> 4) + t * (bin & 15)) & 15);
+        const unsigned long long x = U0 + (unsigned long long)t * I - ((unsigned long long)(wraps & 15u) << 32) - L;
+        const uint32_t r = (uint32_t)(x >> 4) - (nvoices << 27);
+        const uint32_t f = blockIdx.x * TL + t;
+        if (f < nframes) {
+            bus[f] = (int32_t)r;
+            bus_next[f] = 0;
+        }
+        wraps += w[j];
     }
     if (blockIdx.x == 0 && tid == 0 && mode_flag)
         *mode_flag = (MXs < (13u << 25) && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
@@ -695,8 +721,13 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
 {
     // which slot layout did this launch fill?  (written by the main kernel that ran, stable here)
     if (ran_long && *ran_long != 0u) {
-        if (blockIdx.x * SAW_LONG < nframes)
-            saw_finalize_long(reinterpret_cast<SawPartialL *>(partial), bus, bus_next, nframes, nvoices, mode_flag);
+        if (*ran_long == 1u) {
+            if (blockIdx.x * 256u < nframes)
+                saw_finalize_long<256>(reinterpret_cast<SawPartialL<256> *>(partial), bus, bus_next, nframes, nvoices, mode_flag);
+        } else {
+            if (blockIdx.x * 1024u < nframes)
+                saw_finalize_long<1024>(reinterpret_cast<SawPartialL<1024> *>(partial), bus, bus_next, nframes, nvoices, mode_flag);
+        }
         return;
     }
     if (blockIdx.x * 64u >= nframes) return;
@@ -955,7 +986,8 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                 // long launches: the stepping form in 64-frame chunks and the event form in 256-frame
                 // chunks (divisions paid once per 256 frames) are queued, the flag picks one; the
                 // finalize kernel reads from `ran_long` which slot layout was filled
-                const uint32_t gyl = (nframes + SAW_LONG - 1) / SAW_LONG;
+                const uint32_t tl = nframes >= 1024 ? 1024u : 256u;          // chunk length of the event form
+                const uint32_t gyl = (nframes + tl - 1) / tl;
                 const uint32_t *f = (no_events || force_events) ? nullptr : flag;
                 if (!force_events) {
                     if (nt) SMX_CARRY_LAUNCH(true, true, 64, false, f); else SMX_CARRY_LAUNCH(false, true, 64, false, f);
@@ -963,11 +995,12 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                 if (!no_events) {
                     uint32_t gxl = ((cg ? (uint32_t)atoi(cg) : 8192u) + gyl - 1) / gyl;
                     if (gxl > (ngroups + 255) / 256) gxl = (ngroups + 255) / 256;
-                    auto *partl = reinterpret_cast<SawPartialL *>(part);
-                    if (nt) hipLaunchKernelGGL(saw_bank_event_long_kernel<true>, dim3(gxl, gyl), dim3(256), 0, stream,
-                                               d_inc, d_state_in, partl, ngroups, tbase, f, ran_long);
-                    else    hipLaunchKernelGGL(saw_bank_event_long_kernel<false>, dim3(gxl, gyl), dim3(256), 0, stream,
-                                               d_inc, d_state_in, partl, ngroups, tbase, f, ran_long);
+#define SMX_LONG_LAUNCH(NT_, TL_)                                                                            \
+    hipLaunchKernelGGL((saw_bank_event_long_kernel<NT_, TL_>), dim3(gxl, gyl), dim3(256), 0, stream, d_inc, \
+                       d_state_in, reinterpret_cast<SawPartialL<TL_> *>(part), ngroups, tbase, f, ran_long)
+                    if (tl == 1024) { if (nt) SMX_LONG_LAUNCH(true, 1024); else SMX_LONG_LAUNCH(false, 1024); }
+                    else            { if (nt) SMX_LONG_LAUNCH(true, 256);  else SMX_LONG_LAUNCH(false, 256); }
+#undef SMX_LONG_LAUNCH
                 }
             } else if (nframes > 32) {
                 // 64-frame chunks: both forms are queued, the device-side flag picks one (the other

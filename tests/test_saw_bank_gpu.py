@@ -223,9 +223,9 @@ def test_long_block_forms_agree(smx, orc, inc_table, form):
     not care), on all-wrap / never-wrap / half-scale increments, with voices off, over single
     chunks, partial chunks and multi-chunk launches, and across a reload of the increments.
     A 2^25-voice bank for blocks up to 200 frames (64-frame chunks), a 2^22-voice bank for 256
-    frames and more (256-frame chunks in the event form)."""
+    frames and more (256-frame chunks in the event form, 1024-frame chunks from 1024 frames)."""
     for n, piano_blocks, hard_blocks in (((1 << 25) + 2048, [64, 64, 130, 33, 64, 1, 200], [64, 64, 100]),
-                                         ((1 << 22) + 1024, [256, 256, 300, 64, 513, 1000], [256, 257, 600])):
+                                         ((1 << 22) + 1024, [256, 256, 300, 64, 513, 1000, 1024, 1500, 2049], [256, 257, 600, 1025])):
         inc, state = synthetic.saw_bank(n, 0x5EED0E0E, inc_table, active_fraction=0.9)
         bank = smx.SawBank(n)
         bank.set_block_form(form)
@@ -382,7 +382,7 @@ def test_randomised_long_blocks_big_banks(smx, orc, inc_table):
     for trial in range(4 * int(os.environ.get("SMX_FUZZ_ROUNDS", "1"))):
         big = trial % 2 == 1
         n = ((1 << 24) + 2048) if big else ((1 << 22) + 1024)
-        lengths = [33, 63, 64, 65, 127, 128, 200, 255, 256, 300] if big else [256, 257, 300, 511, 512, 513, 700]
+        lengths = [33, 63, 64, 65, 127, 128, 200, 255, 256, 300] if big else [256, 257, 300, 511, 512, 513, 700, 1023, 1024, 1100]
         inc, state = synthetic.saw_bank(n, 0xB160 + trial + seed, inc_table, active_fraction=float(rng.choice([0.5, 1.0])))
         bank = smx.SawBank(n)
         bank.set_block_form(int(rng.integers(0, 3)))
