@@ -179,7 +179,10 @@ def also_workloads(sta, synthetic, tab, big_bank, voices):
                     # above 32 frames the device picks between stepping and locating the wraps: DESIGN 3.2b)
                     "formulation": ("carry (stepping / wrap events, picked on the device)" if frames > 32 else "carry (stepping)")
                                    if frames > 16 and voices * frames >= 1 << 30 else "direct",
-                    "int_valu_frac": round(vs * (1.5 if frames > 16 and voices * frames >= 1 << 30 else 2.5)
+                    # share of the int32 vector issue rate at the stepping forms' instructions per
+                    # voice-sample; not defined when the wraps are located instead of stepped
+                    "int_valu_frac": None if frames > 32 and voices * frames >= 1 << 30 else
+                                     round(vs * (1.5 if frames > 16 and voices * frames >= 1 << 30 else 2.5)
                                            / 1e12 / INT_VALU_PEAK_TOPS, 4),
                     "max_voices_48k": int(vs / 48000)})
     # the same 64-frame blocks on a bank of high voices only (MIDI notes 100..127: 3..17 wraps per voice
