@@ -101,6 +101,97 @@ def load_ref_pdm():
     return lib
 
 
+class RefVoice(C.Structure):                 # linux/synth.c:33-36
+    _fields_ = [("note_inc", C.c_uint32), ("note_state", C.c_uint32)]
+
+
+class RefSynth(C.Structure):                 # linux/synth.c:37-40 (1024 bytes)
+    _fields_ = [("note2voice", C.c_int * 128), ("voice", RefVoice * 64)]
+
+    def arrays(self):
+        """(note2voice int32[128], inc u32[64], state u32[64]) copies."""
+        v = np.frombuffer(bytes(self.voice), np.uint32).reshape(64, 2)
+        return np.array(self.note2voice[:], np.int32), v[:, 0].copy(), v[:, 1].copy()
+
+
+def load_ref_synth():
+    """The SYNTH section of the reference's linux/synth.c (:27-208), compiled verbatim into
+    oracle/_ref/libref_synth.so by oracle/Makefile (None if absent).  note_to_inc() writes a
+    LOG line to stderr per call (linux/synth.c:123)."""
+    so = os.path.join(_HERE, "_ref", "libref_synth.so")
+    if os.path.isdir("/root/reference"):
+        build()
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    P = C.POINTER(RefSynth)
+    lib.synth_init.argtypes = [P]
+    lib.synth_note_on.argtypes = [P, C.c_int]
+    lib.synth_note_off.argtypes = [P, C.c_int]
+    lib.synth_run.argtypes = [P, _f32p, C.c_int]
+    lib.sum_tick_saw.argtypes = [P]; lib.sum_tick_saw.restype = C.c_float
+    lib.sum_tick_square.argtypes = [P]; lib.sum_tick_square.restype = C.c_float
+    lib.voice_alloc.argtypes = [P]; lib.voice_alloc.restype = C.c_int
+    lib.note_to_inc.argtypes = [C.c_int]; lib.note_to_inc.restype = C.c_uint32
+    lib.ref_midi_tab = (C.c_uint8 * 128).in_dll(lib, "midi_tab")
+    return lib
+
+
+class RefPmeas:
+    """struct pmeas_state of the reference's pmeas.h (:10-28) as a raw buffer; field offsets
+    come from the compiled reference itself (ref_pmeas_layout)."""
+    FIELDS = ("log_max", "write", "read", "avg0", "num0", "avg1", "num1", "num", "accu", "last_cc")
+
+    def __init__(self, lib, log_max):
+        lay = np.zeros(11, np.uint32)
+        lib.ref_pmeas_layout(lay)
+        self._off = dict(zip(self.FIELDS, (int(x) for x in lay[:10])))
+        self.buf = np.zeros(int(lay[10]) // 4 + 1, np.uint32)
+        self.lib = lib
+        self.set("log_max", log_max)
+
+    def get(self, k):
+        return int(self.buf[self._off[k] // 4])
+
+    def set(self, k, v):
+        self.buf[self._off[k] // 4] = v
+
+    def update(self, cc):
+        self.lib.ref_pmeas_update(self.buf.ctypes.data, int(cc) & 0xFFFFFFFF)
+
+    def snapshot(self):
+        return [self.get(k) for k in self.FIELDS]
+
+
+def load_ref_pmeas():
+    """pmeas_update of the reference's stm32f103/pmeas.h (:64-108), compiled verbatim into
+    oracle/_ref/libref_pmeas.so (None if absent)."""
+    so = os.path.join(_HERE, "_ref", "libref_pmeas.so")
+    if os.path.isdir("/root/reference"):
+        build()
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    lib.ref_pmeas_update.argtypes = [C.c_void_p, C.c_uint32]
+    lib.ref_pmeas_layout.argtypes = [_u32p]
+    return lib
+
+
+class quiet_stderr:
+    """Silences fd 2 (the reference's note_to_inc LOGs every call, linux/synth.c:123)."""
+    def __enter__(self):
+        import sys
+        sys.stderr.flush()
+        self._saved = os.dup(2)
+        self._null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self._null, 2)
+
+    def __exit__(self, *a):
+        os.dup2(self._saved, 2)
+        os.close(self._saved)
+        os.close(self._null)
+
+
 # ---- convenience wrappers ---------------------------------------------------
 def synth_run(lib, inc, state, nframes, want_vec=True):
     """Runs orc_synth_run in place on state; returns (bus int32[n], vec f32[n])."""

@@ -11,11 +11,16 @@
  *     compiled from where it lies (oracle/_ref, see oracle/Makefile).
  *   - carry-out PDM: checked against the only known-answer the reference
  *     holds, the X=3 row of the comment at stm32f103/mod_pdm.c:43-47.
- *   - synth_run / note_to_inc: restatement of linux/synth.c (unbuildable
- *     here: needs uc_tools macros.h + JACK headers).  Checked against the
- *     known-answers SURVEY.md Appendix A.2 recorded from the reference.
- *   - mod_pdm_pwm.c / mod_controlrate.c / pmeas.h / mod_osc.c: restatement
- *     only (ARM + uc_tools HAL; unbuildable) -- "parity unpinned".
+ *   - note_tab / midi_tab / note_to_inc / voice_alloc / note_on / note_off /
+ *     sum_tick_saw / sum_tick_square / synth_run: checked against the REAL
+ *     linux/synth.c:27-208 (its SYNTH section needs system headers only),
+ *     compiled verbatim into oracle/_ref/libref_synth.so: committed outputs
+ *     tests/golden/synth_c_reference.npz + a live random differential test.
+ *   - pmeas_update: checked against the REAL stm32f103/pmeas.h:64-108
+ *     (oracle/_ref/libref_pmeas.so): tests/golden/pmeas_reference.npz + live.
+ *   - mod_pdm_pwm.c / mod_controlrate.c / mod_osc.c (sub-osc toggle, hard
+ *     sync) / pwm_update / cproc.h / clock.c: restatement only (ARM +
+ *     uc_tools HAL + metastruct.h; unbuildable) -- "parity unpinned".
  *   - dither (uc_tools xorshift.h, absent): always an explicit input.
  *   - poly voice (LPF+ADSR): build-defined extension, no reference.
  *

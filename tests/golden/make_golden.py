@@ -9,6 +9,11 @@ for the pdm.h vectors): `python tests/golden/make_golden.py`.
                             compiled from /root/reference where it lies).
  synth_run_derived.npz      regression vectors of THIS repo's restatement of
                             linux/synth.c (derived, not reference output).
+ synth_c_reference.npz      outputs of the REAL linux/synth.c:27-208 (oracle/_ref/libref_synth.so,
+                            compiled verbatim from /root/reference): note_to_inc(0..127), midi_tab,
+                            float bits + final voice[] + note2voice[] of scripted sequences.
+ pmeas_reference.npz        struct pmeas_state after every call of the REAL pmeas_update
+                            (stm32f103/pmeas.h:64-108, oracle/_ref/libref_pmeas.so).
 """
 import json
 import os
@@ -102,8 +107,127 @@ def synth_run_derived():
                         vec=np.concatenate(vecs), inc=inc, state=st, note2voice=n2v)
 
 
+# ---- linux/synth.c:27-208 and pmeas.h:64-108, compiled VERBATIM into oracle/_ref ------------
+# op codes of a script row [op, a, b]
+OP_ON, OP_OFF, OP_RUN, OP_SQUARE, OP_POKE = 0, 1, 2, 3, 4
+
+
+def synth_scripts():
+    """Scripted note-on/off/run sequences: allocator quirks (steal voice 0
+    when full, stray note-off silences voice 0, note % 128, phase not reset by note_on),
+    >= 16 full-scale voices so the reference's `int sum` wraps, B in {1, 64, 4096},
+    sum_tick_square."""
+    rng = np.random.default_rng(0x5EED0C)
+    s = {}
+    s["b1_ticks"] = ([(OP_ON, 69, 0)] + [(OP_RUN, 1, 0)] * 5 + [(OP_ON, 72, 0), (OP_RUN, 1, 0),
+                     (OP_ON, 76, 0)] + [(OP_RUN, 1, 0)] * 8 + [(OP_OFF, 69, 0)] + [(OP_RUN, 1, 0)] * 4 +
+                     [(OP_OFF, 5, 0), (OP_RUN, 1, 0), (OP_ON, 69 + 128, 0), (OP_RUN, 1, 0),
+                      (OP_OFF, 72 + 256, 0)] + [(OP_RUN, 1, 0)] * 3)
+    q = [(OP_ON, 60, 0), (OP_RUN, 64, 0), (OP_ON, 64, 0), (OP_ON, 67, 0), (OP_RUN, 64, 0), (OP_OFF, 64, 0),
+         (OP_RUN, 1, 0), (OP_OFF, 99, 0), (OP_RUN, 64, 0)]                      # stray note-off
+    q += [(OP_ON, n, 0) for n in range(20, 90)] + [(OP_RUN, 256, 0)]            # > 64 notes: steals voice 0
+    q += [(OP_OFF, n, 0) for n in range(20, 90, 3)] + [(OP_RUN, 64, 0)]
+    q += [(OP_ON, 127, 0), (OP_ON, 0, 0), (OP_ON, 127, 0), (OP_RUN, 64, 0), (OP_OFF, 127, 0), (OP_RUN, 64, 0)]
+    s["b64_quirks"] = q
+    q = [(OP_ON, int(n), 0) for n in rng.integers(0, 128, 40)] + [(OP_RUN, 4096, 0)]
+    q += [(OP_OFF, int(n), 0) for n in rng.integers(0, 128, 30)] + [(OP_RUN, 4096, 0)]
+    q += [(OP_ON, int(n), 0) for n in rng.integers(30, 100, 50)] + [(OP_RUN, 4096, 0)]
+    s["b4096_random"] = q
+    # 64 voices sounding, phases near +full scale / -full scale: the int sum wraps (linux/synth.c:171-176)
+    q = [(OP_ON, n, 0) for n in range(64, 128)]
+    q += [(OP_POKE, v, 0x7FFFFF00 - 977 * v) for v in range(64)] + [(OP_RUN, 64, 0)]
+    q += [(OP_POKE, v, 0x80000000 + 4099 * v) for v in range(64)] + [(OP_RUN, 64, 0)]
+    q += [(OP_POKE, v, int(x)) for v, x in enumerate(rng.integers(0, 2**32, 64))] + [(OP_RUN, 1, 0), (OP_RUN, 64, 0)]
+    s["wrapping_mix"] = q
+    q = [(OP_ON, 40, 0), (OP_SQUARE, 300, 0), (OP_ON, 47, 0), (OP_ON, 52, 0), (OP_SQUARE, 300, 0),
+         (OP_OFF, 40, 0), (OP_SQUARE, 64, 0), (OP_RUN, 64, 0), (OP_OFF, 47, 0), (OP_OFF, 52, 0), (OP_SQUARE, 8, 0)]
+    s["square"] = q
+    return {k: np.array(v, np.int64) for k, v in s.items()}
+
+
+def run_script_on_reference(ref, script):
+    import ctypes as C
+    x = oracle.RefSynth()
+    ref.synth_init(C.byref(x))
+    out = []
+    with oracle.quiet_stderr():
+        for op, a, b in script:
+            a = int(a)
+            if op == OP_ON:
+                ref.synth_note_on(C.byref(x), a)
+            elif op == OP_OFF:
+                ref.synth_note_off(C.byref(x), a)
+            elif op == OP_RUN:
+                v = np.zeros(a, np.float32)
+                ref.synth_run(C.byref(x), v, a)
+                out.append(v)
+            elif op == OP_SQUARE:
+                out.append(np.array([ref.sum_tick_square(C.byref(x)) for _ in range(a)], np.float32))
+            elif op == OP_POKE:
+                x.voice[a].note_state = int(b)
+    n2v, inc, st = x.arrays()
+    return np.concatenate(out), n2v, inc, st
+
+
+def synth_c_reference():
+    ref = oracle.load_ref_synth()
+    if ref is None:
+        print("oracle/_ref/libref_synth.so absent and /root/reference not present: skipped")
+        return
+    out = {"_provenance": np.array("outputs of /root/reference/linux/synth.c:27-208 compiled verbatim "
+                                   "(oracle/Makefile ref) with gcc -O2 -fwrapv; generator tests/golden/make_golden.py")}
+    with oracle.quiet_stderr():
+        out["note_to_inc"] = np.array([ref.note_to_inc(n) for n in range(128)], np.uint32)
+    out["midi_tab"] = np.array(ref.ref_midi_tab[:], np.uint8)
+    for name, script in synth_scripts().items():
+        vec, n2v, inc, st = run_script_on_reference(ref, script)
+        out[name + "_script"] = script
+        out[name + "_vec_bits"] = vec.view(np.uint32)
+        out[name + "_note2voice"] = n2v
+        out[name + "_inc"] = inc
+        out[name + "_state"] = st
+    np.savez_compressed(os.path.join(HERE, "synth_c_reference.npz"), **out)
+
+
+def pmeas_traces():
+    """Timestamp series for pmeas_update: steady, jittered, periods longer than the
+    window, a 32-bit cycle-counter wrap, several log_max."""
+    rng = np.random.default_rng(0x5EED0E)
+    t = {}
+    t["steady_1000_lm14"] = (14, np.cumsum(np.full(200, 1000, np.uint64)))
+    t["jitter_lm26"] = (26, np.cumsum(rng.integers(160000, 170000, 1500).astype(np.uint64)))      # ~440 Hz @ 72 MHz
+    t["slow_lm10"] = (10, np.cumsum(rng.integers(500, 3000, 300).astype(np.uint64)))             # period > window
+    t["wrap_lm20"] = (20, 0xFFF00000 + np.cumsum(rng.integers(1000, 90000, 400).astype(np.uint64)))
+    t["mixed_lm16"] = (16, np.cumsum(np.concatenate([rng.integers(1, 50, 300), rng.integers(20000, 70000, 50),
+                                                     rng.integers(1, 5000, 300)]).astype(np.uint64)))
+    t["lm30"] = (30, np.cumsum(rng.integers(2**24, 2**28, 300).astype(np.uint64)))
+    return {k: (lm, (cc & 0xFFFFFFFF).astype(np.uint32)) for k, (lm, cc) in t.items()}
+
+
+def pmeas_reference():
+    ref = oracle.load_ref_pmeas()
+    if ref is None:
+        print("oracle/_ref/libref_pmeas.so absent and /root/reference not present: skipped")
+        return
+    out = {"_provenance": np.array("state of struct pmeas_state after every pmeas_update call of "
+                                   "/root/reference/stm32f103/pmeas.h:64-108 compiled verbatim (oracle/Makefile ref)"),
+           "fields": np.array(oracle.RefPmeas.FIELDS)}
+    for name, (lm, cc) in pmeas_traces().items():
+        p = oracle.RefPmeas(ref, lm)
+        snap = np.zeros((len(cc), len(oracle.RefPmeas.FIELDS)), np.uint32)
+        for i, c in enumerate(cc):
+            p.update(c)
+            snap[i] = p.snapshot()
+        out[name + "_log_max"] = np.uint32(lm)
+        out[name + "_cc"] = cc
+        out[name + "_trace"] = snap
+    np.savez_compressed(os.path.join(HERE, "pmeas_reference.npz"), **out)
+
+
 if __name__ == "__main__":
     survey_known_answers()
     pdm_h_reference()
     synth_run_derived()
+    synth_c_reference()
+    pmeas_reference()
     print(sorted(os.listdir(HERE)))
