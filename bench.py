@@ -3,26 +3,36 @@
 linux/synth.c:169-202 widened to N voices), one JSON line on rank 0.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over the whole resident bank: one
-synth_run() block of --frames frames for --voices voices per GPU, state in HBM
-before the timed region starts and left there after it.  Voices shard
-contiguously over ranks (weak scaling: --voices is per GPU); each rank mixes
-its shard to an int32 bus and the buses are summed with one RCCL all-reduce
-per step on a second stream (integer sum => bit-exact in any order).
+One process per GPU.  `--gpus N` with N > 1 starts its N ranks itself (fresh child processes,
+before anything touches a GPU); under `python -m torch.distributed.run --nproc-per-node N ...`
+the ranks it is given (RANK / LOCAL_RANK / WORLD_SIZE) are used as they are.  No torch in either
+case: the library creates its own RCCL communicator from a 128-byte id that the ranks exchange
+over a localhost socket (synth_tools_amd/rendezvous.py), which also carries the barrier and the
+max over ranks of the timing.
+
+A "step" is one pass of the hot path over the whole resident bank: one synth_run() block of
+--frames frames for --voices voices per GPU, state in HBM before the timed region starts and
+left there after it.  Voices shard contiguously over ranks (weak scaling: --voices is per GPU);
+each rank mixes its shard to an int32 bus and the buses are summed by RCCL all-reduces on a second
+stream (integer sum => bit-exact in any order; one collective per 8 steps).
 
 Metric: Gsamples/s = voice-samples advanced per second, whole job.
-Roofline: algorithmic HBM bytes per step (8 B read per voice: inc and the lazily
-materialised phase base; nothing written back; + 4 B per bus frame) / average kernel time measured with HIP
-events on the bank's own stream, against 8 TB/s.
-cpu_baseline: the CPU oracle (a port of the reference loop), timed on this
-box's host cores on a bounded sample of the same bank (baseline only).
+Roofline: algorithmic HBM bytes per step (8 B read per voice: inc and the lazily materialised
+phase base; nothing written back; + 4 B per bus frame) / average kernel time
+measured with HIP events on the bank's own stream, against 8 TB/s.
+After the timed region one more step runs and its BUS (the timed kernel's only output) is
+compared with the closed form sum_v ((int32)(state0 + T*inc) >> 4) computed in numpy; a mismatch
+exits non-zero.  The secondary workloads are checked the same way.
+cpu_baseline: the reference's own linux/synth.c (compiled verbatim into oracle/_ref; "reference")
+or the oracle's port of it ("port"), timed on this box's host cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -33,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 INT_VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 16 int32 lanes/clk/SIMD (measured: profiles/)
+ALL_LEGS = ("saw_frames", "saw_hi", "c2", "c5", "c3", "c3_streams", "pwm", "c4")
 
 
 def parse():
@@ -43,16 +54,173 @@ def parse():
     ap.add_argument("--voices", type=int, default=1 << 26, help="voices per GPU")
     ap.add_argument("--frames", type=int, default=1, help="frames per step (1 = tick(), 64 = JACK process())")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--legs", default=",".join(ALL_LEGS), help="secondary workloads to run: " + ",".join(ALL_LEGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-verify", action="store_true", help="skip the bus checks (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves, before any GPU call
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    """Parent of a `python bench.py --gpus N` run: N fresh children (never an exec of a process that
+    touched the GPU; this one never does), rank 0 prints the JSON line on our stdout."""
+    rdzv = tempfile.mkdtemp(prefix="smx_rdzv_")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="0", SMX_RDZV_DIR=rdzv)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                for o in sorted(live):
+                    procs[o].terminate()             # exactly the children we started
+        time.sleep(0.05)
+    try:
+        for f in os.listdir(rdzv):
+            os.unlink(os.path.join(rdzv, f))
+        os.rmdir(rdzv)
+    except OSError:
+        pass
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# closed forms (numpy) the outputs of the timed kernels are checked against
+# ---------------------------------------------------------------------------------------------
+def wrap_i32(x):
+    return ((np.asarray(x, np.int64) + (1 << 31)) % (1 << 32) - (1 << 31)).astype(np.int64)
+
+
+def saw_bus_closed_form(inc, state0, t_first, frames):
+    """sum_tick_saw (linux/synth.c:169-179) at the frames `t_first + f`: the phasor is linear, so
+    phase(t) = state0 + t*inc mod 2^32; int32 wrapping sum of (int)phase >> 4 over the voices that are on."""
+    on = inc != 0
+    out = np.zeros(len(frames), np.int64)
+    with np.errstate(over="ignore"):
+        for k, f in enumerate(frames):
+            ph = state0 + np.uint32((t_first + int(f)) & 0xFFFFFFFF) * inc
+            out[k] = int(np.where(on, ph.view(np.int32) >> 4, 0).sum(dtype=np.int64))
+    return wrap_i32(out)
+
+
+def pdm_rows_closed_form(sp, accu0, dither, rows):
+    """Carry-out PDM (mod_pdm.c:214-244, 259-264): accu(t) = accu0 + sum_{k<=t} (sp + d_k) mod 2^32 and the
+    pulse of tick t is the carry of that add: accu(t) < (sp + d_t).  -> packed words of the given rows."""
+    n = len(sp)
+    out = []
+    with np.errstate(over="ignore"):
+        cum = np.cumsum(dither.astype(np.uint64)) if dither is not None else None
+        for t in rows:
+            d_t = np.uint32(dither[t]) if dither is not None else np.uint32(0)
+            dsum = np.uint32(int(cum[t]) & 0xFFFFFFFF) if dither is not None else np.uint32(0)
+            spd = sp + d_t
+            acc = accu0 + np.uint32((t + 1) & 0xFFFFFFFF) * sp + dsum
+            bits = (acc < spd).astype(np.uint8)
+            out.append(np.packbits(bits.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1))
+    return out
+
+
+def poly_block_numpy(a, nframes):
+    """The build-defined poly voice (no reference counterpart) for one block, vectorised
+    over voices: saw -> 1-pole LPF (two roundings, never fused) -> integer ADSR -> int stereo mix."""
+    inc, phase = a["inc"].copy(), a["phase"].copy()
+    y, co = a["y"].copy(), a["a"]
+    level, stage = a["level"].copy(), a["stage"].copy()
+    on = inc != 0
+    g1 = a["gate"] != 0
+    stage = np.where(on & g1 & ((stage == 0) | (stage == 4)), 1, stage)
+    stage = np.where(on & ~g1 & (stage != 0), 4, stage).astype(np.uint32)
+    pl = (a["pan"] & 0xFFFF).astype(np.int64)
+    pr = (a["pan"] >> 16).astype(np.int64)
+    bus = np.zeros((nframes, 2), np.int64)
+    ar, dr, sl, rr = a["ar"], a["dr"], a["sl"], a["rr"]
+    with np.errstate(over="ignore"):
+        for i in range(nframes):
+            x = phase.view(np.int32).astype(np.float32) * np.float32(2.0 ** -31)
+            phase = np.where(on, phase + inc, phase)
+            t = x - y
+            y = np.where(on, y + co * t, y).astype(np.float32)
+            nl = level + ar
+            a_wrap = nl < level
+            lv_a = np.where(a_wrap, np.uint32(0xFFFFFFFF), nl)
+            st_a = np.where(a_wrap, 2, 1)
+            d_arr = (level <= sl) | ((level - sl) <= dr)
+            lv_d = np.where(d_arr, sl, level - dr)
+            st_d = np.where(d_arr, 3, 2)
+            r_arr = level <= rr
+            lv_r = np.where(r_arr, np.uint32(0), level - rr)
+            st_r = np.where(r_arr, 0, 4)
+            lv = np.select([stage == 1, stage == 2, stage == 3, stage == 4], [lv_a, lv_d, sl, lv_r], np.uint32(0))
+            st = np.select([stage == 1, stage == 2, stage == 3, stage == 4], [st_a, st_d, 3, st_r], 0)
+            level = np.where(on, lv, level).astype(np.uint32)
+            stage = np.where(on, st, stage).astype(np.uint32)
+            g = (level >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+            o = (y * g).astype(np.float32)
+            q = np.where(on, (o * np.float32(524288.0)).astype(np.int32), 0).astype(np.int64)
+            bus[i, 0] = int((q * pl).sum())
+            bus[i, 1] = int((q * pr).sum())
+    return wrap_i32(bus)
+
+
+def roof(alg_bytes, ms, valu_ops=None):
+    """Roofline block of one launch: algorithmic HBM bytes and (optionally) int32 vector lane-ops per launch
+    against the two ceilings; `bound` names the nearer one."""
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    r = {"algorithmic_bytes": float(alg_bytes), "kernel_ms": round(ms, 5), "hbm_GBs": round(gbs, 1),
+         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "int_valu_frac": None, "bound": "hbm"}
+    if valu_ops:
+        r["int_valu_frac"] = round(valu_ops / (ms * 1e-3) / 1e12 / INT_VALU_PEAK_TOPS, 4)
+        if r["int_valu_frac"] > r["hbm_frac"]:
+            r["bound"] = "int-valu issue"
+    return r
+
+
 def saw_roofline(voices, frames, kernel_ms):
-    # 8 B read per voice (inc + state0; the advanced phase is never written back: DESIGN.md §2)
+    # 8 B read per voice (inc + state0; the advanced phase is never written back: DESIGN.md 2)
     alg_bytes = 8.0 * voices + 4.0 * frames
     gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
     return alg_bytes, gbs
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baselines (the only place the oracle package is used)
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline_reference(inc, state, budget_s):
+    """The reference itself: linux/synth.c:27-208 compiled verbatim (oracle/_ref/libref_synth.so), its
+    64-voice struct synth filled with the first 64 voices of the bank, synth_run in 64-frame blocks."""
+    import ctypes as C
+    import oracle
+    ref = oracle.load_ref_synth()
+    if ref is None:
+        return None
+    x = oracle.RefSynth()
+    ref.synth_init(C.byref(x))
+    for v in range(64):
+        x.voice[v].note_inc = int(inc[v])
+        x.voice[v].note_state = int(state[v])
+    vec = np.zeros(64, np.float32)
+    t0, blocks = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        for _ in range(2000):
+            ref.synth_run(C.byref(x), vec, 64)
+        blocks += 2000
+    dt = time.perf_counter() - t0
+    return {"value": round(64 * 64 * blocks / dt / 1e9, 4), "unit": "Gsamples/s", "cores": 1, "kind": "reference",
+            "sample": "linux/synth.c:27-208 compiled verbatim (gcc -O2 -fwrapv), its 64 voices = the first 64 voices "
+                      "of the bank, synth_run in 64-frame blocks, %d blocks" % blocks}
 
 
 def cpu_baseline_saw(inc, state, frames, budget_s):
@@ -101,22 +269,10 @@ def cpu_baseline_saw(inc, state, frames, budget_s):
 
 
 def cpu_baselines_extra(synthetic, tab, budget_s=2.0):
-    """BASELINE.md §3 rows B1 and B4 on one core: the reference's own operating point (64 voices,
-    64-frame blocks) and the carry-out PDM loop (dither 0) on 65 536 channels."""
+    """BASELINE.md 3 row B4 on one core: the carry-out PDM loop (dither 0) on 65 536 channels."""
     import oracle
     orc = oracle.load()
     out = []
-    inc = tab[30:94].astype(np.uint32).copy()                    # notes 30..93 all on
-    st = np.zeros(64, np.uint32)
-    bus = np.zeros(64, np.int32)
-    t0, blocks = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s:
-        for _ in range(2000):
-            orc.orc_synth_run(inc, st, 64, None, bus.ctypes.data, 64)
-        blocks += 2000
-    dt = time.perf_counter() - t0
-    out.append({"workload": "B1: reference operating point, 64 voices x 64-frame blocks (linux/synth.c), 1 core",
-                "value": round(64 * 64 * blocks / dt / 1e9, 4), "unit": "Gsamples/s", "cores": 1, "kind": "port"})
     sp, ac = synthetic.pdm_bank(65536, 0x5EED0003)
     words = 65536 // 32
     bits = np.zeros(64 * words, np.uint32)
@@ -131,23 +287,65 @@ def cpu_baselines_extra(synthetic, tab, budget_s=2.0):
     return out
 
 
-def time_saw(sta, bank, frames, steps, warmup, comm=False, settle_ms=10.0):
+# ---------------------------------------------------------------------------------------------
+# timing helpers
+# ---------------------------------------------------------------------------------------------
+class Saw:
+    """A saw bank plus what the bus check needs: the loaded arrays and the frames run since."""
+
+    def __init__(self, sta, voices, inc, state, device=0):
+        self.bank = sta.SawBank(voices, device=device)
+        self.bank.load(inc, state)
+        self.inc, self.state0, self.t = inc, state, 0
+        self.voices = voices
+
+    def run_async(self, frames):
+        self.bank.run_async(frames)
+        self.t += frames
+
+    def rebase(self):
+        """After a reload of the increments: phases as the bank holds them now."""
+        self.inc, self.state0 = self.bank.read()
+        self.t = 0
+
+    def verify(self, frames, what, rdzv=None, comm=False, pick=None):
+        """One more block; its bus (summed over ranks when comm) against the closed form."""
+        t_first = self.t
+        self.run_async(frames)
+        if comm:
+            self.bank.allreduce_async(frames)
+        bus, _ = self.bank.fetch(frames)
+        pick = list(range(frames)) if pick is None else pick
+        want = saw_bus_closed_form(self.inc, self.state0, t_first, pick)
+        if rdzv is not None and rdzv.world > 1:
+            parts = rdzv.allgather(want.astype("<i8").tobytes())
+            want = wrap_i32(sum(np.frombuffer(p, "<i8") for p in parts))
+        ok = bool(np.array_equal(bus[pick].astype(np.int64), want))
+        if rdzv is not None:
+            ok = rdzv.all_ok(ok)
+        if not ok:
+            sys.exit("bench.py: BUS CHECK FAILED (%s): the timed kernel's output differs from the closed form" % what)
+        return len(pick)
+
+
+def time_saw(saw, frames, steps, warmup, comm=False, settle_ms=10.0):
     """Average ms per step over `steps` steps.  The secondary workloads follow read-backs and CPU
     work that leave the GPU idle, and the first milliseconds after an idle gap run up to 15 % slow
     (clock ramp): besides the `warmup` steps, untimed steps are run until `settle_ms` have passed."""
+    bank = saw.bank
     t0 = time.perf_counter()
     for _ in range(warmup):
-        bank.run_async(frames)
+        saw.run_async(frames)
         if comm:
             bank.allreduce_async(frames)
     bank.sync()
     while (time.perf_counter() - t0) * 1e3 < settle_ms:
         for _ in range(max(1, warmup)):
-            bank.run_async(frames)
+            saw.run_async(frames)
         bank.sync()
     bank.timer_start()
     for _ in range(steps):
-        bank.run_async(frames)
+        saw.run_async(frames)
         if comm:
             bank.allreduce_async(frames)
     ms = bank.timer_stop()
@@ -165,206 +363,246 @@ def settle(step, sync, ms=10.0):
             return
 
 
-def also_workloads(sta, synthetic, tab, big_bank, voices):
+def saw_entry(workload, voices, frames, ms, valu_per_vs, extra=None):
+    vs = voices * frames / (ms * 1e-3)
+    e = {"workload": workload, "value": round(vs / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
+         "max_voices_48k": int(vs / 48000),
+         "roofline": roof(8.0 * voices + 4.0 * frames, ms, valu_per_vs * voices * frames if valu_per_vs else None),
+         "verified": "bus == closed form"}
+    e["hbm_frac"] = e["roofline"]["hbm_frac"]
+    if extra:
+        e.update(extra)
+    return e
+
+
+# ---------------------------------------------------------------------------------------------
+# secondary workloads: every BASELINE config on one GPU, each with its own roofline block
+# ---------------------------------------------------------------------------------------------
+def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
     out = []
-    # the JACK operating point (48 kHz, 64 frames: linux/jack_midi.c:19-20) on the same bank
-    for frames in (16, 32, 64, 1024):
-        ms = time_saw(sta, big_bank, frames, 50 if frames < 1024 else 5, 5 if frames < 1024 else 1)
-        _, gbs = saw_roofline(voices, frames, ms)
-        vs = voices * frames / (ms * 1e-3)
-        out.append({"workload": "saw bank, %d voices, %d frames/step" % (voices, frames),
-                    "value": round(vs / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
-                    "hbm_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                    # vector ops per voice-sample: 2.5 (direct) / 1.5 + 1 scalar (carry formulation, stepping;
-                    # above 32 frames the device picks between stepping and locating the wraps: DESIGN 3.2b)
-                    "formulation": ("carry (stepping / wrap events, picked on the device)" if frames > 32 else "carry (stepping)")
-                                   if frames > 16 and voices * frames >= 1 << 30 else "direct",
-                    # share of the int32 vector issue rate at the stepping forms' instructions per
-                    # voice-sample; not defined when the wraps are located instead of stepped
-                    "int_valu_frac": None if frames > 32 and voices * frames >= 1 << 30 else
-                                     round(vs * (1.5 if frames > 16 and voices * frames >= 1 << 30 else 2.5)
-                                           / 1e12 / INT_VALU_PEAK_TOPS, 4),
-                    "max_voices_48k": int(vs / 48000)})
-    # the same 64-frame blocks on a bank of high voices only (MIDI notes 100..127: 3..17 wraps per voice
-    # per block): the device-side statistic keeps the stepping form, whose time does not depend on the data
-    r = synthetic.splitmix64(0x5EED0009, voices)
-    hi_inc = np.ascontiguousarray(tab[100 + (r % np.uint64(28)).astype(np.int64)].astype(np.uint32))
-    big_bank.load(inc=hi_inc)
-    ms = time_saw(sta, big_bank, 64, 50, 5)
-    out.append({"workload": "saw bank, %d voices, 64 frames/step, notes 100..127 only (stepping form picked on the device)" % voices,
-                "value": round(voices * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5)})
-    # BASELINE config 2: 65 536 voices, 64-frame blocks
-    inc, st = synthetic.saw_bank(65536, 0x5EED0002, tab)
-    b = sta.SawBank(65536)
-    b.load(inc, st)
-    ms = time_saw(sta, b, 64, 200, 20)
-    b.close()
-    out.append({"workload": "c2: saw bank, 65536 voices, 64 frames/step (launch-bound)",
-                "value": round(65536 * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s",
-                "ms_per_step": round(ms, 5)})
-    b = sta.SawBank(65536)
-    b.load(inc, st)
-    ms = time_saw(sta, b, 4096, 50, 5)
-    b.close()
-    out.append({"workload": "c2: saw bank, 65536 voices, 4096 frames/launch (64 JACK blocks per launch, time-parallel chunks)",
-                "value": round(65536 * 4096 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s",
-                "ms_per_step": round(ms, 5)})
-    # BASELINE config 5's per-GPU shard: 8 Mi voices over 8 GPUs = 1 Mi voices each
-    inc, st = synthetic.saw_bank(1 << 20, 0x5EED0005, tab)
-    b = sta.SawBank(1 << 20)
-    b.load(inc, st)
-    for frames in (1, 64):
-        ms = time_saw(sta, b, frames, 200, 20)
-        out.append({"workload": "c5 shard: saw bank, 1048576 voices (1/8 of 8 Mi), %d frame(s)/step" % frames,
-                    "value": round((1 << 20) * frames / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s",
-                    "ms_per_step": round(ms, 5)})
-    b.close()
-    # BASELINE config 3: 1 Mi PDM channels (mod_pdm.c integer path), dither 0 and seeded
-    n, nt = 1 << 20, 4096
-    sp, ac = synthetic.pdm_bank(n, 0x5EED0003)
-    p = sta.PdmBank(n)
-    p.load(sp, ac)
-    for with_d in (False, True):
-        if with_d:
-            # seeded dither for the perf leg only: parity tests cover explicit dither arrays
-            p.tick_n(64, synthetic.dither_stream(64, 7, 0x0FFFFFFF), want_bits=False)
-        settle(lambda: p.tick_n_async(nt, with_d), p.sync)
-        p.timer_start()
-        reps = 20
-        for _ in range(reps):
-            p.tick_n_async(nt, with_d)
-        ms = p.timer_stop() / reps
-        alg = 12.0 * n + nt * n / 8.0
-        out.append({"workload": "c3: carry-out PDM bank, %d channels, %d ticks/launch, dither=%s" % (n, nt, "seeded" if with_d else "0"),
-                    "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
-                    "ms_per_step": round(ms, 4), "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
-                    "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-    # the same bank with channel-stream output (no transpose: 2 instead of 3 vector ops per tick)
-    for with_d in (False, True):
-        settle(lambda: p.tick_n_streams_async(nt, with_d), p.sync)
-        p.timer_start()
+    SMX_FORM_AUTO, SMX_FORM_STEPPING = 0, 1
+    if "saw_frames" in legs:
+        # longer blocks of the same bank; 64 frames = the JACK operating point (linux/jack_midi.c:19-20)
+        for frames in (8, 16, 32, 64, 1024):
+            carry = frames > 16 and voices * frames >= 1 << 30
+            for form in ((SMX_FORM_STEPPING, SMX_FORM_AUTO) if (carry and frames > 32) else (SMX_FORM_STEPPING,)):
+                big.bank.set_block_form(form)
+                reps = 50 if frames < 1024 else 5
+                ms = time_saw(big, frames, reps, 5 if frames < 1024 else 1)
+                if form == SMX_FORM_AUTO:          # a few launches until the device-side statistic has settled
+                    ms = time_saw(big, frames, reps, 5 if frames < 1024 else 1)
+                if verify:
+                    big.verify(frames, "saw bank %d frames" % frames, pick=sorted({0, frames // 2, frames - 1}))
+                # vector instructions per voice-sample of the stepping forms (profiles/*insts*): 2.5 direct, 1.5 + 1
+                # scalar in the carry formulation; not defined when the wraps are located instead of stepped
+                valu = None if form == SMX_FORM_AUTO else (1.5 if carry else 2.5)
+                out.append(saw_entry(
+                    "saw bank, %d voices, %d frames/step%s" % (voices, frames, ", form AUTO (wrap events picked on the device)"
+                                                               if form == SMX_FORM_AUTO else ""),
+                    voices, frames, ms, valu,
+                    {"formulation": ("carry, wrap events (AUTO)" if form == SMX_FORM_AUTO else "carry, stepping (default: "
+                                     "data-independent run time)") if carry else "direct"}))
+        big.bank.set_block_form(SMX_FORM_STEPPING)
+    if "saw_hi" in legs:
+        # the same 64-frame blocks on a bank of high voices only (MIDI notes 100..127: 3..17 wraps per voice per
+        # block): AUTO keeps the stepping form there, whose time does not depend on the data
+        r = synthetic.splitmix64(0x5EED0009, voices)
+        hi_inc = np.ascontiguousarray(tab[100 + (r % np.uint64(28)).astype(np.int64)].astype(np.uint32))
+        big.bank.load(inc=hi_inc)
+        big.rebase()
+        big.bank.set_block_form(SMX_FORM_AUTO)
+        ms = time_saw(big, 64, 50, 5)
+        if verify:
+            big.verify(64, "saw bank, high notes", pick=[0, 31, 63])
+        big.bank.set_block_form(SMX_FORM_STEPPING)
+        out.append(saw_entry("saw bank, %d voices, 64 frames/step, notes 100..127 only, form AUTO (stepping picked on the device)"
+                             % voices, voices, 64, ms, 1.5))
+    if "c2" in legs:
+        # BASELINE config 2: 65 536 voices, 64-frame blocks
+        inc, st = synthetic.saw_bank(65536, 0x5EED0002, tab)
+        b = Saw(sta, 65536, inc, st)
+        ms = time_saw(b, 64, 200, 20)
+        if verify:
+            b.verify(64, "c2")
+        out.append(saw_entry("c2: saw bank, 65536 voices, 64 frames/step (BASELINE configs[1] as written)", 65536, 64, ms, 2.5,
+                             {"bound_note": "launch-bound: 512 KiB of state and 0.1 us of arithmetic per launch; the kernel "
+                                            "floor of an empty launch is ~2-3 us"}))
+        out[-1]["roofline"]["bound"] = "launch latency"
+        ms = time_saw(b, 4096, 50, 5)
+        if verify:
+            b.verify(4096, "c2 x 4096 frames", pick=[0, 1, 63, 64, 2047, 4095])
+        out.append(saw_entry("c2: saw bank, 65536 voices, 4096 frames/launch (64 JACK blocks per launch, time-parallel chunks)",
+                             65536, 4096, ms, 2.5))
+        b.bank.close()
+    if "c5" in legs:
+        # BASELINE config 5's per-GPU shard: 8 Mi voices over 8 GPUs = 1 Mi voices each
+        inc, st = synthetic.saw_bank(1 << 20, 0x5EED0005, tab)
+        b = Saw(sta, 1 << 20, inc, st)
+        for frames in (1, 64):
+            ms = time_saw(b, frames, 200, 20)
+            if verify:
+                b.verify(frames, "c5 shard %d frames" % frames)
+            out.append(saw_entry("c5 shard: saw bank, 1048576 voices (1/8 of 8 Mi), %d frame(s)/step" % frames,
+                                 1 << 20, frames, ms, 2.5))
+        b.bank.close()
+    if "c3" in legs or "c3_streams" in legs:
+        # BASELINE config 3: 1 Mi PDM channels (mod_pdm.c integer path), dither 0 and seeded
+        n, nt = 1 << 20, 4096
+        sp, ac = synthetic.pdm_bank(n, 0x5EED0003)
+        p = sta.PdmBank(n)
+        p.load(sp, ac)
+        dith = synthetic.dither_stream(nt, 7, 0x0FFFFFFF)          # mod_pdm.c:261 mask
+        for layout in ("tick-major",) * ("c3" in legs) + ("channel-stream",) * ("c3_streams" in legs):
+            run = p.tick_n_async if layout == "tick-major" else p.tick_n_streams_async
+            for with_d in (False, True):
+                if with_d:
+                    # seeded dither for the perf leg (the generator is uc_tools': never claimed); parity tests
+                    # cover explicit dither arrays
+                    p.tick_n(nt, dith, want_bits=False)
+                settle(lambda: run(nt, with_d), p.sync)
+                p.timer_start()
+                reps = 20
+                for _ in range(reps):
+                    run(nt, with_d)
+                ms = p.timer_stop() / reps
+                checked = None
+                if verify:
+                    _, a0 = p.read()
+                    rows = [0, 1, 31, 32, nt // 2, nt - 1]
+                    want = pdm_rows_closed_form(sp, a0, dith if with_d else None, rows)
+                    if layout == "tick-major":
+                        got = p.tick_n(nt, dith if with_d else None)
+                        ok = all(np.array_equal(got[t], w) for t, w in zip(rows, want))
+                    else:
+                        got = p.tick_n_streams(nt, dith if with_d else None)
+                        ok = all(np.array_equal((got[t // 32] >> np.uint32(t % 32)) & 1,
+                                                np.unpackbits(w.view(np.uint8), bitorder="little"))
+                                 for t, w in zip(rows, want))
+                    if not ok:
+                        sys.exit("bench.py: PDM CHECK FAILED (%s, dither=%s)" % (layout, with_d))
+                    checked = "pulse rows %s == closed form" % rows
+                alg = 12.0 * n + nt * n / 8.0
+                # vector instructions per 64 channel-ticks: 3 (v_add_co + 2 v_writelane) tick-major, 2 channel-stream
+                e = {"workload": "c3: carry-out PDM bank, %d channels, %d ticks/launch, %s layout, dither=%s"
+                                 % (n, nt, layout, "seeded" if with_d else "0"),
+                     "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
+                     "ms_per_step": round(ms, 4),
+                     "roofline": roof(alg, ms, (3.0 if layout == "tick-major" else 2.0) * n * nt + (n * nt if with_d else 0)),
+                     "verified": checked}
+                e["hbm_frac"] = e["roofline"]["hbm_frac"]
+                out.append(e)
+        p.close()
+    if "pwm" in legs:
+        # noise-shaped PWM bank (mod_pdm_pwm.c: pdm2 + glide + control rate), 1 Mi channels
+        n, nt = 1 << 20, 1024
+        w = sta.PwmBank(n, order=2)
+        w.load(setpoint=synthetic.pdm_bank(n, 0x5EED0008)[0])
+        w.tick_n(8, synthetic.dither_stream(8, 7, 0x3FF), want_duty=False)
+        settle(lambda: w.tick_n_async(nt, True), w.sync)
+        w.timer_start()
         for _ in range(20):
-            p.tick_n_streams_async(nt, with_d)
-        ms = p.timer_stop() / 20
-        alg = 12.0 * n + nt * n / 8.0
-        out.append({"workload": "c3: carry-out PDM bank, %d channels, %d ticks/launch, channel-stream layout, dither=%s" % (n, nt, "seeded" if with_d else "0"),
-                    "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
-                    "ms_per_step": round(ms, 4), "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
-                    "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-    p.close()
-    # noise-shaped PWM bank (mod_pdm_pwm.c: pdm2 + glide + control rate), 1 Mi channels
-    n, nt = 1 << 20, 1024
-    w = sta.PwmBank(n, order=2)
-    w.load(setpoint=synthetic.pdm_bank(n, 0x5EED0008)[0])
-    w.tick_n(8, synthetic.dither_stream(8, 7, 0x3FF), want_duty=False)
-    settle(lambda: w.tick_n_async(nt, True), w.sync)
-    w.timer_start()
-    for _ in range(20):
-        w.tick_n_async(nt, True)
-    ms = w.timer_stop() / 20
-    w.close()
-    alg = 52.0 * n + float(nt) * n
-    out.append({"workload": "noise-shaped PWM bank (pdm2+glide), %d channels, %d ticks/launch, dither seeded" % (n, nt),
-                "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
-                "ms_per_step": round(ms, 4), "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
-                "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-    # BASELINE config 4: 256 Ki poly voices (saw + 1-pole LPF + ADSR + stereo mix; build-defined)
-    n = 1 << 18
-    pb = sta.PolyBank(n)
-    pb.load(**synthetic.poly_bank(n, 0x5EED0004, tab))
-    settle(lambda: pb.run_async(64), pb.sync)
-    pb.timer_start()
-    reps = 200
-    for _ in range(reps):
-        pb.run_async(64)
-    ms = pb.timer_stop() / reps
-    pb.close()
-    alg = 60.0 * n + 64 * 8
-    out.append({"workload": "c4: poly bank (saw+LPF+ADSR, stereo), %d voices, 64 frames/step" % n,
-                "value": round(n * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
-                "hbm_GBs": round(alg / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            w.tick_n_async(nt, True)
+        ms = w.timer_stop() / 20
+        w.close()
+        e = {"workload": "noise-shaped PWM bank (pdm2+glide), %d channels, %d ticks/launch, dither seeded" % (n, nt),
+             "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
+             "ms_per_step": round(ms, 4), "roofline": roof(52.0 * n + float(nt) * n, ms, 6.06 * n * nt),
+             "verified": None}
+        e["hbm_frac"] = e["roofline"]["hbm_frac"]
+        out.append(e)
+    if "c4" in legs:
+        # BASELINE config 4: 256 Ki poly voices (saw + 1-pole LPF + ADSR + stereo mix; build-defined)
+        n = 1 << 18
+        pb = sta.PolyBank(n)
+        arrs = synthetic.poly_bank(n, 0x5EED0004, tab)
+        pb.load(**arrs)
+        settle(lambda: pb.run_async(64), pb.sync)
+        pb.timer_start()
+        reps = 200
+        for _ in range(reps):
+            pb.run_async(64)
+        ms = pb.timer_stop() / reps
+        checked = None
+        if verify:
+            cur = pb.read()
+            cur["gate"] = arrs["gate"]
+            want = poly_block_numpy(cur, 64)
+            got, _ = pb.run(64)
+            if not np.array_equal(got.reshape(64, 2).astype(np.int64), want):
+                sys.exit("bench.py: POLY CHECK FAILED: the stereo bus differs from the numpy statement of DESIGN 3.5")
+            checked = "stereo bus == numpy statement of the build's own definition (not reference parity)"
+        pb.close()
+        e = {"workload": "c4: poly bank (saw+LPF+ADSR, stereo; build-defined), %d voices, 64 frames/step" % n,
+             "value": round(n * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
+             "roofline": roof(60.0 * n + 64 * 8, ms, 19.0 * n * 64), "verified": checked}
+        e["hbm_frac"] = e["roofline"]["hbm_frac"]
+        out.append(e)
     return out
 
 
-def main():
+# ---------------------------------------------------------------------------------------------
+def run_rank(a):
     # stdout carries exactly ONE line (the JSON): libraries that print banners at init (RCCL
     # prints its version block to stdout) are pointed at stderr for the whole run.
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (a.gpus, a.gpus))
-        a.gpus = world
+    a.gpus = world
 
-    import torch
     import synth_tools_amd as sta
-    from synth_tools_amd import synthetic
+    from synth_tools_amd import rendezvous, synthetic
 
-    if not torch.cuda.is_available():
-        sys.exit("bench.py: no GPU visible (there is no CPU fallback)")
-    torch.cuda.set_device(local)
-    dist = None
-    # SMX_BENCH_FORCE_DIST: rehearse the N > 1 control path (torch process group + in-library RCCL
-    # communicator in one process) with a single rank under torch.distributed.run
-    force_dist = world == 1 and bool(os.environ.get("SMX_BENCH_FORCE_DIST")) and "MASTER_ADDR" in os.environ
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    L = sta.lib()
+    ndev = L.smx_device_count()
+    if ndev <= local:
+        sys.exit("bench.py: rank %d: no GPU visible for local rank %d (%d device(s); there is no CPU fallback)"
+                 % (rank, local, ndev))
+    rdzv = rendezvous.Rendezvous(rank, world)
 
-    tab = synthetic.note_inc_table(sta.lib().note_to_inc)
+    tab = synthetic.note_inc_table(L.note_to_inc)
     # rank r owns voices [r*V, (r+1)*V) of the global bank: its own splitmix64 stream
     inc, state = synthetic.saw_bank(a.voices, 0x5EED0005 + 0x1000 * rank, tab)
-    bank = sta.SawBank(a.voices, device=local)
-    bank.load(inc, state)
+    saw = Saw(sta, a.voices, inc, state, device=local)
+    bank = saw.bank
 
-    if dist:
-        uid = torch.zeros(sta.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.from_numpy(sta.comm_unique_id()))
-        dist.broadcast(uid, 0)
-        bank.comm_init(rank, world, uid.cpu().numpy())
-
-    comm = dist is not None
-    if not comm and os.environ.get("SMX_BENCH_FORCE_COMM"):
+    comm = world > 1
+    if comm:
+        uid = rdzv.broadcast(sta.comm_unique_id().tobytes() if rank == 0 else b"")
+        bank.comm_init(rank, world, np.frombuffer(uid, np.uint8).copy())
+    elif os.environ.get("SMX_BENCH_FORCE_COMM"):
         # rehearsal of the multi-GPU code path on one GPU: 1-rank RCCL communicator
         bank.comm_init(0, 1, sta.comm_unique_id())
         comm = True
+    ranks_seen = bank.comm_ranks() if comm else 1
     for _ in range(a.warmup):
-        bank.run_async(a.frames)
+        saw.run_async(a.frames)
         if comm:
             bank.allreduce_async(a.frames)
     bank.sync()
 
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    rdzv.barrier()
+    L.smx_device_synchronize(local)
     t0 = time.perf_counter()
     bank.timer_start()
     for _ in range(a.steps):
-        bank.run_async(a.frames)
+        saw.run_async(a.frames)
         if comm:
             bank.allreduce_async(a.frames)
     kernel_ms = bank.timer_stop() / a.steps        # HIP events on the kernel's stream
-    bank.sync()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    bank.sync()                                    # issues what is still queued, both streams idle
+    L.smx_device_synchronize(local)
+    rdzv.barrier()
     dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, kernel_ms = float(t[0]), float(t[1])
+    dt, kernel_ms = rdzv.max_floats([dt, kernel_ms])
 
-    # sanity on the timed state: phases advanced by exactly (warmup+steps)*frames*inc
-    _, gst = bank.read()
-    total_frames = (a.warmup + a.steps) * a.frames
-    ok = bool(np.array_equal(gst[:1 << 16], (state[:1 << 16] + np.uint32(total_frames) * inc[:1 << 16])))
-    if not ok:
-        sys.exit("bench.py: phase check failed after the timed region")
+    # the timed kernel's only output is the bus: one more step, compared with the closed form
+    checked = 0
+    if not a.no_verify:
+        checked = saw.verify(a.frames, "headline, %d voices x %d frames" % (a.voices, a.frames), rdzv=rdzv, comm=comm,
+                             pick=None if a.frames <= 8 else sorted({0, a.frames // 2, a.frames - 1}))
+    collectives, block_sums = bank.comm_stats() if comm else (0, 0)
 
     if rank == 0:
         vs = world * a.voices * a.frames * a.steps / dt
@@ -388,12 +626,21 @@ def main():
                        "voices_per_gpu": a.voices, "frames_per_step": a.frames,
                        "voices_total": world * a.voices,
                        "baseline_config": "BASELINE configs[1] (int32 phase-accumulator saw voices on 1 MI355X, "
-                                          "bit-exact) scaled from 65 536 voices (512 KiB, launch-bound: see `also`) to an "
-                                          "HBM-resident bank, the regime the %HBM-roofline metric is defined in",
-                       "parallelism": "voices sharded x%d, int32 bus all-reduce (RCCL)" % world if comm else "1 GPU"},
+                                          "bit-exact) scaled from 65 536 voices (512 KiB, launch-bound) to an "
+                                          "HBM-resident bank, the regime the %HBM-roofline metric is defined in; every "
+                                          "BASELINE config as written is a line of `also` with its own roofline block",
+                       "parallelism": "voices sharded x%d, int32 bus all-reduce (RCCL), one collective per %d steps"
+                                      % (world, max(1, block_sums // max(1, collectives))) if comm else "1 GPU"},
             "max_voices_48k": int(vs / 48000),
+            "ranks_seen": ranks_seen,
+            "multi_gpu_measured": "this line" if world > 1 else "no N > 1 run is part of this line",
+            "verified": ("bus of one more step == closed form sum_v ((int32)(state0 + T*inc) >> 4), %d frame(s), %d voices%s"
+                         % (checked, world * a.voices, " summed over %d ranks" % world if world > 1 else ""))
+                        if checked else None,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "recorded: profiles/traffic.json (rocprofv3 --pmc passes of this command), "
+                                           "not measured in this run" if traffic else None,
                          "kernel": "saw_bank_kernel", "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_voice": 8,
@@ -401,20 +648,36 @@ def main():
                                  "state0 + elapsed*inc and never written back, so SURVEY 8d's 4-byte state write "
                                  "(12 B/voice) does not exist on this path; PMC traffic agrees (profiles/)"},
         }
+        if comm:
+            line["collectives"] = {"issued": collectives, "block_sums_carried": block_sums}
         if world == 1 and not a.no_cpu:
+            ref = cpu_baseline_reference(inc, state, min(a.cpu_seconds, 4.0))
             single, par = cpu_baseline_saw(inc, state, a.frames, a.cpu_seconds)
-            line["cpu_baseline"] = single
+            line["cpu_baseline"] = ref if ref else single
+            line["cpu_baseline_port"] = single
             line["cpu_baseline_parallel"] = par
             line["cpu_baselines_extra"] = cpu_baselines_extra(synthetic, tab)
         if world == 1 and not a.no_also:
-            line["also"] = also_workloads(sta, synthetic, tab, bank, a.voices)
+            legs = [x for x in a.legs.split(",") if x]
+            also = also_workloads(sta, synthetic, tab, saw, a.voices, legs, not a.no_verify)
+            line["also"] = also
+            cfg = [e for e in also if e["workload"].startswith(("c2:", "c3:", "c4:", "c5 "))]
+            line["config"]["baseline_configs_vs_50pct_hbm"] = {
+                "meet": [e["workload"] for e in cfg if e["roofline"]["hbm_frac"] >= 0.5],
+                "miss": [{"workload": e["workload"], "hbm_frac": e["roofline"]["hbm_frac"], "bound": e["roofline"]["bound"]}
+                         for e in cfg if e["roofline"]["hbm_frac"] < 0.5]}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    if dist:
-        dist.barrier()          # every rank is done with its communicator before any is torn down
+    rdzv.barrier()              # every rank is done with its communicator before any is torn down
     bank.close()
-    if dist:
-        dist.destroy_process_group()
+    rdzv.close()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
+    run_rank(a)
 
 
 if __name__ == "__main__":

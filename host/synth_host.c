@@ -88,7 +88,11 @@ static void bank_fill(smx_bank *b, uint32_t n) {
     ASSERT(inc && st);
     for (uint32_t v = 0; v < n; v++) {
         uint32_t h = v * 2654435761u;
-        inc[v] = note_to_inc(21 + (int)((h >> 12) % 88u));
+        /* SYNTH_FILL=worst: every voice wraps 12 times per 64 frames (increment 12/64 of 2^32), the
+           bank on which locating the wraps costs most; anything else: piano range */
+        const char *fill = getenv("SYNTH_FILL");
+        inc[v] = (fill && !strcmp(fill, "worst")) ? (0x30000000u | (h & 0xFFFFu))
+                                                  : note_to_inc(21 + (int)((h >> 12) % 88u));
         st[v] = h * 40503u + 12345u;
     }
     ASSERT(0 == smx_bank_load(b, inc, st));
@@ -173,6 +177,7 @@ int main(int argc, char **argv) {
         audio_out = FAKE_AUDIO_PORT;
         if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
         if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
+        if (bank && getenv("SYNTH_FORM_AUTO")) ASSERT(0 == smx_bank_set_block_form(bank, SMX_FORM_AUTO));
         if (bank && getenv("SYNTH_FILL")) bank_fill(bank, (uint32_t)voices);
         synth_init(&synth);
         FILE *out = fopen(argv[5], "wb");
@@ -193,6 +198,9 @@ int main(int argc, char **argv) {
                 fake.cur[fake.ncur].buffer = e->bytes;
                 fake.ncur++;
             }
+            /* more than 1024 events in one block: the surplus is dropped (a JACK MIDI port buffer is
+               bounded too), never carried into a later block and never left to stall the cursor */
+            while (fake.cursor < fake.nev && fake.ev[fake.cursor].block <= fake.block) fake.cursor++;
             struct timespec ta, tb;
             if (period_ns) {
                 next.tv_nsec += period_ns;
@@ -221,6 +229,7 @@ int main(int argc, char **argv) {
         ASSERT(audio_out = jack.port_register(client, "audio_out", JACK_DEFAULT_AUDIO_TYPE, JackPortIsOutput, 0));
         if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
         if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
+        if (bank && getenv("SYNTH_FORM_AUTO")) ASSERT(0 == smx_bank_set_block_form(bank, SMX_FORM_AUTO));
         if (bank && getenv("SYNTH_FILL")) bank_fill(bank, (uint32_t)voices);
         synth_init(&synth);
         jack.set_process_callback(client, process, 0);

@@ -42,6 +42,7 @@ extern "C" {
 const char *smx_last_error(void);
 int  smx_device_count(void);             /* 0 when no GPU is visible      */
 int  smx_version(void);
+int  smx_device_synchronize(int device); /* all streams of the device idle */
 
 /* ======================================================================== */
 /* 1. Linux drop-in: linux/synth.c:31-45, 145-208                           */
@@ -125,8 +126,12 @@ int smx_bank_set_block_mode(smx_bank *b, int mode);
  * (linux/synth.c:172-179); every form gives the same bits.  STEPPING adds inc frame by frame and
  * counts the carry-outs.  EVENTS locates each wrap directly (first at floor(~phase/inc), then every
  * floor((2^32-1)/inc) or one more frames): much less work for banks of mostly low voices, more for
- * banks of high ones.  AUTO (default) keeps a statistic of the increments on the device and picks
- * per launch; the first long block after smx_bank_load(inc) steps. */
+ * banks of high ones, so its run time depends on the data (up to 3x the stepping form on a bank of
+ * only very high notes).  STEPPING is the default: a real-time caller (the JACK process callback,
+ * linux/synth.c:277-282) gets a run time that does not depend on what is being played.  AUTO keeps a
+ * statistic of the increments on the device and picks per launch (largest increment below MIDI note
+ * ~110 and a mean of at most 2 wraps per voice and 64 frames: events; otherwise stepping); the first
+ * long block after smx_bank_load(inc) steps. */
 #define SMX_FORM_AUTO     0
 #define SMX_FORM_STEPPING 1
 #define SMX_FORM_EVENTS   2
@@ -147,16 +152,31 @@ int smx_bank_timer_stop(smx_bank *b, float *ms);
  * the same interval when nothing else is enqueued on the stream. */
 
 /* ---- multi-GPU: per-GPU mix, then one int32 sum over xGMI (RCCL) -------- */
+/* One process per GPU; rank r's bank holds its contiguous shard of the voices (the voice loop
+ * of linux/synth.c:172-179 is the only data-parallel axis and the mix its only exchange).
+ * SPMD contract: once a bank has a communicator, every rank makes the SAME sequence of
+ * smx_bank_run / _run_async / _allreduce_async / _fetch / _sync / _set_block_mode /
+ * _set_comm_group calls with the same frame counts (like MPI collectives): the calls decide
+ * when the queued sums are issued, and all ranks must issue the same collectives. */
 #define SMX_UNIQUE_ID_BYTES 128
-int smx_comm_unique_id(uint8_t id[SMX_UNIQUE_ID_BYTES]);   /* rank 0 */
+int smx_comm_unique_id(uint8_t id[SMX_UNIQUE_ID_BYTES]);   /* rank 0; hand the bytes to the other ranks */
 int smx_bank_comm_init(smx_bank *b, int rank, int nranks,
                        const uint8_t id[SMX_UNIQUE_ID_BYTES]);
-/* All-reduce (sum, int32) of the last block's bus across ranks, in place in
- * device memory, on a second stream ordered after the block's kernel.  Requests are
- * queued and issued as one grouped RCCL launch per 8 blocks (fewer, larger
- * collectives), or at once when a result is needed (smx_bank_fetch / smx_bank_sync /
- * pipelined smx_bank_run). */
+/* Ranks the communicator really spans (ncclCommCount); 0 without a communicator. */
+int smx_bank_comm_ranks(const smx_bank *b);
+/* All-reduce (sum, int32) of the last block's bus across ranks, in place in device memory, on
+ * a second stream ordered after the block's kernel.  Requests are queued and issued as ONE
+ * all-reduce per group of consecutive blocks (the bus ring is contiguous; default 8 blocks:
+ * fewer, larger collectives -- xGMI is latency-bound at these sizes), or at once when a result
+ * is needed (smx_bank_fetch / smx_bank_sync / smx_bank_run).  With a communicator
+ * smx_bank_run returns the sum over all ranks in both block modes; in SMX_BLOCK_PIPELINED the
+ * reduce and the copy to the host run on the second stream behind the kernel, so the caller
+ * waits for neither. */
 int smx_bank_allreduce_async(smx_bank *b, int n);
+/* Blocks per collective, 1..8 (1: every block's sum is issued at once). */
+int smx_bank_set_comm_group(smx_bank *b, int blocks);
+/* Counters: collectives issued so far and the block sums they carried. */
+int smx_bank_comm_stats(const smx_bank *b, unsigned long long *collectives, unsigned long long *block_sums);
 /* Copy the (reduced) bus to the host and convert as linux/synth.c:180. */
 int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n);
 

@@ -73,6 +73,7 @@ ABI = [
     ("smx_last_error", C.c_char_p, []),
     ("smx_device_count", C.c_int, []),
     ("smx_version", C.c_int, []),
+    ("smx_device_synchronize", C.c_int, [C.c_int]),
     ("synth_note_on", None, [C.POINTER(Synth), C.c_int]),
     ("synth_note_off", None, [C.POINTER(Synth), C.c_int]),
     ("synth_init", None, [C.POINTER(Synth)]),
@@ -104,6 +105,9 @@ ABI = [
     ("smx_comm_unique_id", C.c_int, [_u8]),
     ("smx_bank_comm_init", C.c_int, [_P, C.c_int, C.c_int, _u8]),
     ("smx_bank_allreduce_async", C.c_int, [_P, C.c_int]),
+    ("smx_bank_comm_ranks", C.c_int, [_P]),
+    ("smx_bank_set_comm_group", C.c_int, [_P, C.c_int]),
+    ("smx_bank_comm_stats", C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     ("smx_bank_fetch", C.c_int, [_P, _P, _P, C.c_int]),
     ("smx_pdm_create", _P, [C.c_uint32, C.c_int]),
     ("smx_pdm_destroy", None, [_P]),
@@ -298,6 +302,18 @@ class SawBank:
 
     def allreduce_async(self, n):
         _check(lib().smx_bank_allreduce_async(self._h, n), "smx_bank_allreduce_async")
+
+    def comm_ranks(self):
+        return lib().smx_bank_comm_ranks(self._h)
+
+    def set_comm_group(self, blocks):
+        _check(lib().smx_bank_set_comm_group(self._h, blocks), "smx_bank_set_comm_group")
+
+    def comm_stats(self):
+        """(collectives issued, block sums they carried)."""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        _check(lib().smx_bank_comm_stats(self._h, C.byref(a), C.byref(b)), "smx_bank_comm_stats")
+        return a.value, b.value
 
 
 def comm_unique_id():

@@ -67,6 +67,13 @@ extern "C" int smx_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+// every stream of the device idle (what a benchmark brackets its timed region with)
+extern "C" int smx_device_synchronize(int device)
+{
+    SMX_HIP(hipSetDevice(device));
+    SMX_HIP(hipDeviceSynchronize());
+    return SMX_OK;
+}
 
 // ---------------------------------------------------------------------------
 // Linux drop-in: linux/synth.c:42-45, 145-165, 196-206

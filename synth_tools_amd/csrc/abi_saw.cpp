@@ -91,16 +91,31 @@ struct smx_bank {
     // launch will zero; it was used NBUS-1 blocks ago.  The ring is deep so that the compute
     // stream has to wait for the comm stream only once per NBUS/2 blocks (see
     // bank_bus_release) instead of once per block.
+    // The ring is ONE allocation with a tight stride (the longest block seen, rounded up to 64
+    // frames): consecutive blocks lie side by side, so the sums of a whole group of blocks are
+    // ONE all-reduce over a contiguous range instead of one collective per block (xGMI is
+    // latency-bound at these sizes; the frames between a block's end and the stride are
+    // summed along and ignored).
     static constexpr int NBUS = 16;
-    int32_t *d_bus[NBUS] = {};
+    int32_t *d_ring = nullptr;
+    int32_t *d_bus[NBUS] = {};                   // d_ring + i * bus_cap
     uint32_t bus_zeroed[NBUS] = {};              // leading frames known to be zero
     int bus_cur = 0;
-    uint32_t bus_cap = 0;
+    uint32_t bus_cap = 0;                        // = stride of the ring, in frames
+    uint32_t scratch_cap = 0;                    // frames d_scratch is sized for
     int32_t *h_bus = nullptr;                    // pinned
     // pipelined block mode (smx_bank_set_block_mode): the bus of block k is copied to pinned
     // memory behind its kernel and handed out by the call that launches block k+1
     int block_mode = 0;
-    int block_form = SMX_FORM_AUTO;              // smx_bank_set_block_form
+    int block_form = SMX_FORM_STEPPING;          // smx_bank_set_block_form (default: data-independent run time)
+    // AUTO: the device picks the form per launch and both forms are queued (the loser returns at
+    // once, ~3 us).  The finalize kernel also writes its pick to this pinned word; once the host
+    // has seen the same pick at FORM_STABLE consecutive launches it queues only that form (both
+    // are exact on any bank, so a stale pick costs time, never bits).
+    uint32_t *h_form = nullptr;
+    uint32_t form_seen = 0xFFFFFFFFu;
+    int form_stable = 0;
+    static constexpr int FORM_STABLE = 4;
     int32_t *h_pipe[2] = {nullptr, nullptr};
     uint32_t pipe_cap = 0;
     hipEvent_t ev_pipe[2] = {nullptr, nullptr};
@@ -119,8 +134,11 @@ struct smx_bank {
     int ar_queue[NBUS] = {};                     // bus indices with a requested, not yet issued sum
     int ar_frames[NBUS] = {};
     int ar_count = 0;
+    int comm_group = NBUS / 2;                   // blocks per collective (smx_bank_set_comm_group)
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    int comm_count = 0;                          // ncclCommCount: ranks the communicator really spans
+    unsigned long long ar_launches = 0, ar_blocks = 0;   // collectives issued / block sums they carried
     int note2voice[128];
     smx::FreeMap free_map;
     // smx_bank_midi_events: (voice, increment) pairs of one batch, staged in pinned memory (two
@@ -145,23 +163,28 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
     }
     SMX_HIP(hipStreamSynchronize(b->stream));
     if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
-    const uint32_t cap = smx::round_up(n < 4096 ? 4096 : n, 4096);
+    const uint32_t cap = smx::round_up(n, 64);
+    if (b->d_ring) SMX_HIP(hipFree(b->d_ring));
+    b->d_ring = nullptr;
+    SMX_HIP(hipMalloc((void **)&b->d_ring, (size_t)smx_bank::NBUS * cap * 4));
+    SMX_HIP(hipMemset(b->d_ring, 0, (size_t)smx_bank::NBUS * cap * 4));
     for (int i = 0; i < smx_bank::NBUS; i++) {
-        if (b->d_bus[i]) SMX_HIP(hipFree(b->d_bus[i]));
-        b->d_bus[i] = nullptr;
-        SMX_HIP(hipMalloc((void **)&b->d_bus[i], (size_t)cap * 4));
-        SMX_HIP(hipMemset(b->d_bus[i], 0, (size_t)cap * 4));
+        b->d_bus[i] = b->d_ring + (size_t)i * cap;
         b->bus_zeroed[i] = cap;
         b->comm_pending[i] = false;
     }
     if (b->h_bus) SMX_HIP(hipHostFree(b->h_bus));
     b->h_bus = nullptr;
     SMX_HIP(hipHostMalloc((void **)&b->h_bus, (size_t)cap * 4, hipHostMallocDefault));
-    if (b->d_scratch) SMX_HIP(hipFree(b->d_scratch));
-    b->d_scratch = nullptr;
-    if (b->n_pad >= (1u << 16)) {
-        SMX_HIP(hipMalloc(&b->d_scratch, smx::saw_scratch_bytes(cap)));
-        SMX_HIP(hipMemset(b->d_scratch, 0, smx::saw_scratch_bytes(cap)));   // slots are kept zero between launches
+    // partial-sum slots of the slot / carry formulations: sized for 4096 frames at least, so
+    // that the usual block lengths never reallocate them
+    const uint32_t scap = smx::round_up(n < 4096 ? 4096 : n, 4096);
+    if (b->n_pad >= (1u << 16) && scap > b->scratch_cap) {
+        if (b->d_scratch) SMX_HIP(hipFree(b->d_scratch));
+        b->d_scratch = nullptr;
+        SMX_HIP(hipMalloc(&b->d_scratch, smx::saw_scratch_bytes(scap)));
+        SMX_HIP(hipMemset(b->d_scratch, 0, smx::saw_scratch_bytes(scap)));   // slots are kept zero between launches
+        b->scratch_cap = scap;
     }
     b->bus_cap = cap;
     return SMX_OK;
@@ -191,6 +214,8 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     if ((e = hipMalloc((void **)&b->d_inc, bytes)) != hipSuccess) return fail("hipMalloc inc", e);
     if ((e = hipMalloc((void **)&b->d_state0, bytes)) != hipSuccess) return fail("hipMalloc state", e);
     if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+    if ((e = hipHostMalloc((void **)&b->h_form, 64, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
+    *b->h_form = 0xFFFFFFFFu;
     if ((e = hipEventCreate(&b->ev_t0)) != hipSuccess) return fail("event", e);
     if ((e = hipEventCreate(&b->ev_t1)) != hipSuccess) return fail("event", e);
     for (int i = 0; i < smx_bank::NBUS; i++) {
@@ -203,7 +228,7 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return fail("sync", e);
     memset(b->note2voice, 0, sizeof(b->note2voice));
     b->free_map.reset(b->n, true);
-    if (bank_ensure_bus(b, 4096) != SMX_OK) { smx_bank_destroy(b); return nullptr; }
+    if (bank_ensure_bus(b, 64) != SMX_OK) { smx_bank_destroy(b); return nullptr; }
     return b;
 }
 
@@ -216,12 +241,13 @@ extern "C" void smx_bank_destroy(smx_bank *b)
     if (b->comm) (void)ncclCommDestroy(b->comm);
     if (b->d_inc) (void)hipFree(b->d_inc);
     if (b->d_state0) (void)hipFree(b->d_state0);
+    if (b->d_ring) (void)hipFree(b->d_ring);
     for (int i = 0; i < smx_bank::NBUS; i++) {
-        if (b->d_bus[i]) (void)hipFree(b->d_bus[i]);
         if (b->ev_kernel[i]) (void)hipEventDestroy(b->ev_kernel[i]);
         if (b->ev_comm[i]) (void)hipEventDestroy(b->ev_comm[i]);
     }
     if (b->h_bus) (void)hipHostFree(b->h_bus);
+    if (b->h_form) (void)hipHostFree(b->h_form);
     for (int i = 0; i < 2; i++) {
         if (b->h_pipe[i]) (void)hipHostFree(b->h_pipe[i]);
         if (b->ev_pipe[i]) (void)hipEventDestroy(b->ev_pipe[i]);
@@ -265,6 +291,9 @@ extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *s
         // new increments: the statistic that picks the long-block form is void (stepping until the
         // next long block has measured the new bank)
         if (b->d_scratch) SMX_HIP(hipMemsetAsync(b->d_scratch, 0, smx::saw_scratch_header_bytes(), b->stream));
+        if (b->h_form) *(volatile uint32_t *)b->h_form = 0xFFFFFFFFu;
+        b->form_seen = 0xFFFFFFFFu;
+        b->form_stable = 0;
     }
     if (state)
         SMX_HIP(hipMemcpy(b->d_state0, state, (size_t)b->n * 4, hipMemcpyHostToDevice));
@@ -349,26 +378,39 @@ extern "C" int smx_bank_note_off(smx_bank *b, int note)
         }                                                                      \
     } while (0)
 
-// Issue every queued bus sum as one grouped RCCL launch on the comm stream, ordered after all
-// kernels enqueued so far.  Integer sums: associative, the same bits in any order.
+// Issue every queued bus sum on the comm stream, ordered after all kernels enqueued so far.
+// The queue holds consecutive ring slots (smx_bank_allreduce_async flushes before a gap or the
+// ring's wrap), so the group is ONE all-reduce over [first slot, last slot + its frames): the
+// frames between a block's end and the stride hold zeros or old sums, are summed along and
+// never read.  (A non-consecutive queue cannot arise; it would fall back to one grouped launch
+// of per-block calls.)  Integer sums: associative, the same bits in any order.
 static int bank_comm_flush(smx_bank *b)
 {
     if (b->ar_count == 0) return SMX_OK;
-    const int last = b->ar_queue[b->ar_count - 1];
+    const int first = b->ar_queue[0], last = b->ar_queue[b->ar_count - 1];
     SMX_HIP(hipEventRecord(b->ev_kernel[last], b->stream));
     SMX_HIP(hipStreamWaitEvent(b->comm_stream, b->ev_kernel[last], 0));
-    SMX_NCCL(ncclGroupStart());
-    for (int k = 0; k < b->ar_count; k++) {
-        const int i = b->ar_queue[k];
-        SMX_NCCL(ncclAllReduce(b->d_bus[i], b->d_bus[i], (size_t)b->ar_frames[k], ncclInt32, ncclSum, b->comm,
-                               b->comm_stream));
+    bool run = true;
+    for (int k = 1; k < b->ar_count; k++) run = run && b->ar_queue[k] == b->ar_queue[k - 1] + 1;
+    if (run) {
+        const size_t count = (size_t)(last - first) * b->bus_cap + (size_t)b->ar_frames[b->ar_count - 1];
+        SMX_NCCL(ncclAllReduce(b->d_bus[first], b->d_bus[first], count, ncclInt32, ncclSum, b->comm, b->comm_stream));
+    } else {
+        SMX_NCCL(ncclGroupStart());
+        for (int k = 0; k < b->ar_count; k++) {
+            const int i = b->ar_queue[k];
+            SMX_NCCL(ncclAllReduce(b->d_bus[i], b->d_bus[i], (size_t)b->ar_frames[k], ncclInt32, ncclSum, b->comm,
+                                   b->comm_stream));
+        }
+        SMX_NCCL(ncclGroupEnd());
     }
-    SMX_NCCL(ncclGroupEnd());
     SMX_HIP(hipEventRecord(b->ev_comm[last], b->comm_stream));
     for (int k = 0; k < b->ar_count; k++) {
         b->comm_pending[b->ar_queue[k]] = true;
         b->ev_owner[b->ar_queue[k]] = last;
     }
+    b->ar_launches++;
+    b->ar_blocks += (unsigned long long)b->ar_count;
     b->ar_count = 0;
     return SMX_OK;
 }
@@ -431,8 +473,14 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
     int bi, bnext;
     rv = bank_bus_advance(b, (uint32_t)n, &bi, &bnext);
     if (rv) return rv;
+    int form = b->block_form;
+    if (form == SMX_FORM_AUTO && n > 32 && b->h_form) {
+        const uint32_t seen = *(volatile uint32_t *)b->h_form;          // whatever has landed: no sync
+        if (seen == b->form_seen) b->form_stable++; else { b->form_seen = seen; b->form_stable = 0; }
+        if (b->form_stable >= smx_bank::FORM_STABLE && seen <= 1u) form = seen ? SMX_FORM_EVENTS : SMX_FORM_STEPPING;
+    }
     rv = smx::launch_saw_bank(b->d_inc, b->d_state0, b->d_bus[bi], b->d_bus[bnext], b->n_pad, (uint32_t)n,
-                              b->elapsed, b->d_scratch, b->block_form, b->stream);
+                              b->elapsed, b->d_scratch, form, b->h_form, b->stream);
     if (rv) return rv;
     b->elapsed += (uint32_t)n;             // mod 2^32, like the phases
     b->bus_zeroed[bi] = 0;                 // now holds this block's sums
@@ -596,16 +644,23 @@ static int bank_run_pipelined(smx_bank *b, float *vec, int32_t *bus, int n)
     if (rv) return rv;
     const int cur = b->pipe_k & 1, prev = cur ^ 1;
     const int bi = b->bus_cur;
-    if (bank_ar_queued(b, bi)) {
+    if (b->comm) {
+        // With a communicator the block that is handed out one call later is the SUM over all
+        // ranks: the all-reduce of this block is issued at once on the comm stream and the copy
+        // to pinned memory follows it THERE, so the compute stream goes straight on to the next
+        // block -- the real-time thread waits neither for the kernel nor for the reduce.
+        rv = smx_bank_allreduce_async(b, n);
+        if (rv) return rv;
         rv = bank_comm_flush(b);
         if (rv) return rv;
+        SMX_HIP(hipMemcpyAsync(b->h_pipe[cur], b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->comm_stream));
+        SMX_HIP(hipEventRecord(b->ev_pipe[cur], b->comm_stream));
+        // the buffer is busy until the copy has read it: ev_comm[bi] now completes after the copy
+        SMX_HIP(hipEventRecord(b->ev_comm[b->ev_owner[bi]], b->comm_stream));
+    } else {
+        SMX_HIP(hipMemcpyAsync(b->h_pipe[cur], b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+        SMX_HIP(hipEventRecord(b->ev_pipe[cur], b->stream));
     }
-    if (b->comm_pending[bi]) {
-        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[b->ev_owner[bi]], 0));
-        b->comm_pending[bi] = false;
-    }
-    SMX_HIP(hipMemcpyAsync(b->h_pipe[cur], b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
-    SMX_HIP(hipEventRecord(b->ev_pipe[cur], b->stream));
     b->pipe_n[cur] = n;
     b->pipe_k++;
     const int have = b->pipe_n[prev];
@@ -627,6 +682,10 @@ extern "C" int smx_bank_run(smx_bank *b, float *vec, int32_t *bus, int n)
     }
     int rv = smx_bank_run_async(b, n);
     if (rv) return rv;
+    if (b->comm) {                     // a sharded bank: synth_run returns the sum over all ranks
+        rv = smx_bank_allreduce_async(b, n);
+        if (rv) return rv;
+    }
     return smx_bank_fetch(b, vec, bus, n);
 }
 
@@ -691,7 +750,9 @@ extern "C" int smx_bank_comm_init(smx_bank *b, int rank, int nranks,
     SMX_HIP(hipSetDevice(b->device));
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
+    if (b->comm) { set_error("smx_bank_comm_init: the bank already has a communicator"); return SMX_E_STATE; }
     SMX_NCCL(ncclCommInitRank(&b->comm, nranks, u, rank));
+    SMX_NCCL(ncclCommCount(b->comm, &b->comm_count));
     // (a high-priority stream was measured and makes the overlapped step 50 % slower)
     SMX_HIP(hipStreamCreateWithFlags(&b->comm_stream, hipStreamNonBlocking));
     b->rank = rank;
@@ -706,10 +767,36 @@ extern "C" int smx_bank_allreduce_async(smx_bank *b, int n)
     SMX_HIP(hipSetDevice(b->device));
     const int bi = b->bus_cur;
     if (bank_ar_queued(b, bi) || b->comm_pending[bi]) return SMX_OK;      // already requested for this block
+    // the queue stays a run of consecutive ring slots (one contiguous all-reduce): a gap (a block
+    // without a request in between) or the ring's wrap closes the group first
+    if (b->ar_count && b->ar_queue[b->ar_count - 1] + 1 != bi) {
+        int rv = bank_comm_flush(b);
+        if (rv) return rv;
+    }
     b->ar_queue[b->ar_count] = bi;
     b->ar_frames[b->ar_count] = n;
     b->ar_count++;
-    if (b->ar_count >= smx_bank::NBUS / 2) return bank_comm_flush(b);
+    if (b->ar_count >= b->comm_group) return bank_comm_flush(b);
     return SMX_OK;
 }
 
+extern "C" int smx_bank_set_comm_group(smx_bank *b, int blocks)
+{
+    if (!b || blocks < 1 || blocks > smx_bank::NBUS / 2) { set_error("smx_bank_set_comm_group: %d (1..%d)", blocks, smx_bank::NBUS / 2); return SMX_E_ARG; }
+    if (b->comm) {
+        int rv = bank_comm_flush(b);
+        if (rv) return rv;
+    }
+    b->comm_group = blocks;
+    return SMX_OK;
+}
+
+extern "C" int smx_bank_comm_ranks(const smx_bank *b) { return (b && b->comm) ? b->comm_count : 0; }
+
+extern "C" int smx_bank_comm_stats(const smx_bank *b, unsigned long long *collectives, unsigned long long *block_sums)
+{
+    if (!b) return SMX_E_ARG;
+    if (collectives) *collectives = b->ar_launches;
+    if (block_sums) *block_sums = b->ar_blocks;
+    return SMX_OK;
+}

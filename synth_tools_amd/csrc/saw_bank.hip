@@ -635,7 +635,8 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
 template <uint32_t TL>
 __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ partial, int32_t *__restrict__ bus,
                                                   int32_t *__restrict__ bus_next, uint32_t nframes,
-                                                  uint32_t nvoices, uint32_t *__restrict__ mode_flag)
+                                                  uint32_t nvoices, uint32_t *__restrict__ mode_flag,
+                                                  uint32_t *__restrict__ host_flag)
 {
     constexpr uint32_t FPT = TL / 256;
     __shared__ uint32_t Hs[256], Wsum[4];
@@ -706,8 +707,11 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ 
         }
         wraps += w[j];
     }
-    if (blockIdx.x == 0 && tid == 0 && mode_flag)
-        *mode_flag = (MXs < (13u << 25) && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
+    if (blockIdx.x == 0 && tid == 0 && mode_flag) {
+        const uint32_t f = (MXs < (13u << 25) && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
+        *mode_flag = f;
+        if (host_flag) *host_flag = f;          // pinned host copy: lets the host skip the form that would return at once
+    }
 }
 
 // One workgroup per 64-frame chunk: add the chunk's slots (and clear them for the next
@@ -717,16 +721,16 @@ __global__ __launch_bounds__(256)
 void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
                               int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
                               uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag,
-                              const uint32_t *__restrict__ ran_long)
+                              const uint32_t *__restrict__ ran_long, uint32_t *__restrict__ host_flag)
 {
     // which slot layout did this launch fill?  (written by the main kernel that ran, stable here)
     if (ran_long && *ran_long != 0u) {
         if (*ran_long == 1u) {
             if (blockIdx.x * 256u < nframes)
-                saw_finalize_long<256>(reinterpret_cast<SawPartialL<256> *>(partial), bus, bus_next, nframes, nvoices, mode_flag);
+                saw_finalize_long<256>(reinterpret_cast<SawPartialL<256> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag);
         } else {
             if (blockIdx.x * 1024u < nframes)
-                saw_finalize_long<1024>(reinterpret_cast<SawPartialL<1024> *>(partial), bus, bus_next, nframes, nvoices, mode_flag);
+                saw_finalize_long<1024>(reinterpret_cast<SawPartialL<1024> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag);
         }
         return;
     }
@@ -791,7 +795,9 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         // wraps 269 us, 1 % of the voices at 12 wraps 243 us, all at 12 wraps 750 us.
         if (blockIdx.x == 0 && t == 0 && mode_flag) {
             const uint32_t m = max(max(Mx[0], Mx[1]), max(Mx[2], Mx[3]));
-            *mode_flag = (m < (13u << 25) && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
+            const uint32_t fl = (m < (13u << 25) && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
+            *mode_flag = fl;
+            if (host_flag) *host_flag = fl;
         }
     }
 }
@@ -939,7 +945,7 @@ size_t saw_scratch_bytes(uint32_t max_frames)
 
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
-                    void *d_scratch, int long_block_form, hipStream_t stream)
+                    void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream)
 {
     if (n_pad == 0 || (n_pad & 1023) || nframes == 0) {
         set_error("launch_saw_bank: n_pad=%u nframes=%u", n_pad, nframes);
@@ -1019,7 +1025,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             }
 #undef SMX_CARRY_LAUNCH
             hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
-                               d_bus_next, nframes, n_pad, flag, ran_long);
+                               d_bus_next, nframes, n_pad, flag, ran_long, host_flag);
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         }

@@ -45,9 +45,11 @@ static inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m
 // to force the direct formulation.
 size_t saw_scratch_bytes(uint32_t max_frames);
 // long_block_form: SMX_FORM_AUTO / SMX_FORM_STEPPING / SMX_FORM_EVENTS (include/synth_mi355x.h)
+// host_flag: pinned (device-visible) word that receives the form the device would pick next
+// (0 stepping, 1 events) after every long block, or NULL.
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state0, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
-                    void *d_scratch, int long_block_form, hipStream_t stream);
+                    void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream);
 // leading bytes of the scratch area that hold the formulation flag (zero: stepping form)
 size_t saw_scratch_header_bytes();
 int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state0, uint32_t *d_or_bus,

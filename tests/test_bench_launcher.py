@@ -1,0 +1,96 @@
+"""CPU: `python bench.py --gpus N` starts its own ranks, and the host-side rendezvous the ranks use
+(stdlib sockets; no torch, no GPU call) carries the unique id, the barrier and the max over ranks."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    from synth_tools_amd.rendezvous import Rendezvous
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    r = Rendezvous(rank, world, timeout=30)
+    uid = r.broadcast(bytes(range(128)) if rank == 0 else b"")
+    assert uid == bytes(range(128))
+    parts = r.allgather(("rank%%d" %% rank).encode() * (rank + 1))
+    assert parts == [("rank%%d" %% k).encode() * (k + 1) for k in range(world)]
+    for k in range(50):
+        r.barrier()
+    mx = r.max_floats([float(rank), 10.0 - rank, 1.5])
+    assert mx == [world - 1.0, 10.0, 1.5]
+    assert r.all_ok(True) is True
+    assert r.all_ok(rank != 1) is False
+    r.barrier()
+    r.close()
+    print(json.dumps({"rank": rank, "ok": True}))
+""") % ROOT
+
+
+def _spawn(world, env_extra):
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), **env_extra)
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=60) for p in procs]
+    return [(p.returncode, o, e) for p, (o, e) in zip(procs, outs)]
+
+
+def test_rendezvous_world_4_with_an_explicit_directory(tmp_path):
+    res = _spawn(4, {"SMX_RDZV_DIR": str(tmp_path / "rdzv")})
+    for rc, out, err in res:
+        assert rc == 0, err
+        assert '"ok": true' in out
+    assert not os.path.exists(tmp_path / "rdzv" / "port")          # rank 0 removed it
+
+
+def test_rendezvous_directory_derived_like_under_torchrun():
+    """No SMX_RDZV_DIR: the directory comes from MASTER_PORT and the common parent pid (what the workers
+    of `python -m torch.distributed.run` share); torchrun's own store keeps MASTER_PORT itself."""
+    env = {k: v for k, v in os.environ.items() if k != "SMX_RDZV_DIR"}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29417")
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=60)
+        assert p.returncode == 0, err
+
+
+def test_world_1_needs_no_socket():
+    sys.path.insert(0, ROOT)
+    from synth_tools_amd.rendezvous import Rendezvous
+    r = Rendezvous(0, 1)
+    assert r.allgather(b"x") == [b"x"] and r.broadcast(b"id") == b"id" and r.max_floats([2.0, 3.0]) == [2.0, 3.0]
+    r.barrier()
+    assert r.all_ok(True) and not r.all_ok(False)
+    r.close()
+
+
+def test_bench_gpus_2_starts_two_ranks_with_one_command():
+    """Without a GPU both ranks stop at 'no GPU visible' (there is no CPU fallback); the parent relays the
+    failure as its exit code and prints no JSON line.  What matters here: ONE command, two ranks, each
+    with its own RANK / LOCAL_RANK, nothing re-executed."""
+    import synth_tools_amd
+    if synth_tools_amd.lib().smx_device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is visible: the launcher is exercised by the bench itself")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""
+    assert "rank 0: no GPU visible for local rank 0" in p.stderr
+    assert "rank 1: no GPU visible for local rank 1" in p.stderr
+
+
+def test_bench_does_not_import_torch():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import torch" not in src
+    rdzv = open(os.path.join(ROOT, "synth_tools_amd", "rendezvous.py")).read()
+    assert "import torch" not in rdzv

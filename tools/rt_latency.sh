@@ -7,3 +7,10 @@ for v in 64 65536 1048576 16777216 67108864 268435456; do
   SYNTH_FILL=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync      /"
   SYNTH_FILL=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v SYNTH_PIPELINE=1 ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/pipelined /"
 done
+# worst case for the wrap-event form: every voice at 12 wraps per block.  Default form (stepping): the callback's
+# time does not depend on what is played; SYNTH_FORM_AUTO=1 lets the device pick (it keeps stepping on this bank)
+for v in 16777216 67108864 268435456; do
+  SYNTH_FILL=worst SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync worst-case bank, default form      /"
+  SYNTH_FILL=worst SYNTH_FORM_AUTO=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync worst-case bank, SYNTH_FORM_AUTO=1 /"
+  SYNTH_FILL=1 SYNTH_FORM_AUTO=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync piano-range bank, SYNTH_FORM_AUTO=1 /"
+done
