@@ -328,10 +328,11 @@ class Saw:
         return len(pick)
 
 
-def time_saw(saw, frames, steps, warmup, comm=False, settle_ms=10.0):
+def time_saw(saw, frames, steps, warmup, comm=False, settle_ms=30.0):
     """Average ms per step over `steps` steps.  The secondary workloads follow read-backs and CPU
-    work that leave the GPU idle, and the first milliseconds after an idle gap run up to 15 % slow
-    (clock ramp): besides the `warmup` steps, untimed steps are run until `settle_ms` have passed."""
+    work that leave the GPU idle, and the first 15-25 ms after an idle gap or a change of kernel run
+    up to 30 % slow (tools/explore_settle.py: 64 Mi voices x 16 frames 130 -> 101 us over the first
+    120 launches): besides the `warmup` steps, untimed steps are run until `settle_ms` have passed."""
     bank = saw.bank
     t0 = time.perf_counter()
     for _ in range(warmup):
@@ -353,7 +354,7 @@ def time_saw(saw, frames, steps, warmup, comm=False, settle_ms=10.0):
     return ms / steps
 
 
-def settle(step, sync, ms=10.0):
+def settle(step, sync, ms=30.0):
     """Untimed steps until `ms` have passed (see time_saw): clock ramp after an idle gap."""
     t0 = time.perf_counter()
     while True:

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsynth_mi355x.so")
+LIB_PATH = os.environ.get("SMX_LIB") or os.path.join(_HERE, "libsynth_mi355x.so")   # SMX_LIB: A/B builds (tools/)
 
 _u32 = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")

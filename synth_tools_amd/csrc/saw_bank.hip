@@ -64,6 +64,9 @@ __device__ __forceinline__ T stream_load(const T *p)
 }
 // Partial sums of one 64-frame chunk.  Workgroups add into one of a few slots per chunk
 // (few adders per address); saw_bank_finalize_kernel sums the slots and clears them.
+#ifndef SAW_PFD
+#define SAW_PFD 2
+#endif
 constexpr int SAW_SLOTS = 64;       // slots per chunk (unused ones stay zero)
 struct SawPartial {
     unsigned long long L[64];     // sum over voices of (u_v(t) & 15)
@@ -95,8 +98,11 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     __shared__ int32_t M[TC][65];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
-    const uint32_t t0 = tbase + blockIdx.y * 64u;   // phase offset of this chunk
-    const uint32_t f0 = blockIdx.y * 64u;           // first frame of this chunk (>0 only when TC == 64)
+    // Time is cut into chunks of TC frames on blockIdx.y (the phasor is linear: the phase at the chunk's
+    // first frame is state0 + (tbase + f0) * inc).  Big banks use one chunk per 64 frames; small banks
+    // take shorter chunks so that a block of 64 frames still gives the chip a few hundred workgroups.
+    const uint32_t f0 = blockIdx.y * (uint32_t)TC;  // first frame of this chunk
+    const uint32_t t0 = tbase + f0;                 // phase offset of this chunk
 
     for (uint32_t i = tid; i < TC * 65; i += 256) (&M[0][0])[i] = 0;
     // the bus is accumulated with atomics, so it must start at zero: each launch
@@ -114,17 +120,19 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     // From 8 frames up (SLOT variants) the prefetch runs TWO rows ahead: one row of arithmetic
     // (160..640 cycles x 8 waves per SIMD) is shorter than the HBM latency, and with one row in
     // flight per wave the chip holds 16 MB in flight, ~5 TB/s at most.
-    constexpr bool PF2 = SLOT;
+    // PFD rows are kept in flight per wave (a small queue of register rows, rotated per trip).
+    constexpr int PFD = SLOT ? SAW_PFD : 1;
     const uint32_t nrows = ngroups >> 8;
-    u32x4 a_next = 0, b_next = 0, a_next2 = 0, b_next2 = 0;
+    u32x4 qa[PFD], qb[PFD];
     if constexpr (VW == 4) {
+#pragma unroll
+        for (int k = 0; k < PFD; k++) { qa[k] = 0; qb[k] = 0; }
         if (blockIdx.x < nrows) {
-            a_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + blockIdx.x * 256u + tid);
-            b_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + blockIdx.x * 256u + tid);
-            if constexpr (PF2) {
-                const uint32_t r2 = min(blockIdx.x + gridDim.x, nrows - 1) * 256u + tid;
-                a_next2 = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + r2);
-                b_next2 = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + r2);
+#pragma unroll
+            for (int k = 0; k < PFD; k++) {
+                const uint32_t r = min(blockIdx.x + k * gridDim.x, nrows - 1) * 256u + tid;   // short banks re-read a row
+                qa[k] = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + r);
+                qb[k] = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + r);
             }
         }
     }
@@ -135,17 +143,12 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
         const uint32_t g = (VW == 4) ? gi * 256u + tid : gi;
         uint32_t vi[VW], vs[VW];
         if constexpr (VW == 4) {
-            const u32x4 a = a_next, b = b_next;
-            if constexpr (PF2) {
-                a_next = a_next2; b_next = b_next2;
-                const uint32_t rn = min(gi + 2 * gridDim.x, nrows - 1) * 256u + tid;   // last trips re-read a row
-                a_next2 = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + rn);
-                b_next2 = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + rn);
-            } else {
-                const uint32_t rn = min(gi + gridDim.x, nrows - 1) * 256u + tid;       // last trip re-reads its row
-                a_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + rn);
-                b_next = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + rn);
-            }
+            const u32x4 a = qa[0], b = qb[0];
+#pragma unroll
+            for (int k = 0; k + 1 < PFD; k++) { qa[k] = qa[k + 1]; qb[k] = qb[k + 1]; }
+            const uint32_t rn = min(gi + PFD * gridDim.x, nrows - 1) * 256u + tid;           // last trips re-read a row
+            qa[PFD - 1] = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + rn);
+            qb[PFD - 1] = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + rn);
             vi[0] = a.x; vi[1] = a.y; vi[2] = a.z; vi[3] = a.w;
             vs[0] = b.x; vs[1] = b.y; vs[2] = b.z; vs[3] = b.w;
         } else {
@@ -185,8 +188,9 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     if constexpr (SLOT) {
-        SawPartial *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
-        if (q == 0 && t < TC && f0 + t < nframes) atomicAdd(&out->W[t], (uint32_t)s);
+        // slots are kept per 64 frames: chunk f0 lands in row f0 / 64 at offset f0 % 64 (TC divides 64)
+        SawPartial *out = partial + (size_t)(f0 >> 6) * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
+        if (q == 0 && t < TC && f0 + t < nframes) atomicAdd(&out->W[(f0 & 63u) + t], (uint32_t)s);
     } else {
         if (q == 0 && t < TC && f0 + t < nframes) atomicAdd(&bus[f0 + t], s);
     }
@@ -319,6 +323,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
                            const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
 {
     static_assert(!EVENTS || TC == 64, "the event form is built for 64-frame chunks");
+    static_assert(TC == 32 || TC == 64, "frames per chunk");
     __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
     __shared__ unsigned long long S[2];            // U0, I
@@ -892,7 +897,8 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
               uint32_t n_pad, uint32_t nframes, uint32_t tbase, SawPartial *partial, hipStream_t stream)
 {
     const uint32_t ngroups = n_pad / VW;
-    const uint32_t gy = (nframes + 63) / 64;
+    const uint32_t gy = (nframes + TC - 1) / TC;                 // chunks of TC frames
+    const uint32_t gy64 = (nframes + 63) / 64;                   // slot rows (one per 64 frames)
     const uint32_t rows = (ngroups + 255) / 256;
     if constexpr (VW == 4 && TC >= 8) {
         static const bool no_slots = getenv("SMX_SAW_NO_SLOTS") != nullptr;     // A/B switch
@@ -906,7 +912,7 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
             if (gx > rows) gx = rows;
             hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT, true>), dim3(gx, gy), dim3(256), 0, stream,
                                inc, si, bus, bus_next, ngroups, nframes, tbase, partial);
-            hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3(gy), dim3(256), 0, stream, partial, bus,
+            hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3(gy64), dim3(256), 0, stream, partial, bus,
                                bus_next, nframes);
             SMX_HIP(hipGetLastError());
             return SMX_OK;
@@ -919,16 +925,19 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
     return SMX_OK;
 }
 
+// tc_cap: longest chunk (frames per workgroup pass); blocks longer than that run as several chunks on
+// blockIdx.y.  64 for big banks; small banks take shorter chunks (launch_saw_bank).
 template <int VW, bool NT>
 int launch_vw(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bus_next,
-              uint32_t n_pad, uint32_t nframes, uint32_t tbase, SawPartial *partial, hipStream_t stream)
+              uint32_t n_pad, uint32_t nframes, uint32_t tbase, SawPartial *partial, uint32_t tc_cap, hipStream_t stream)
 {
-    if (nframes > 32) return launch_tc<64, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nframes > 16) return launch_tc<32, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nframes > 8)  return launch_tc<16, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nframes > 4)  return launch_tc<8, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nframes > 2)  return launch_tc<4, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nframes > 1)  return launch_tc<2, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    const uint32_t nf = nframes < tc_cap ? nframes : tc_cap;
+    if (nf > 32) return launch_tc<64, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nf > 16) return launch_tc<32, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nf > 8)  return launch_tc<16, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nf > 4)  return launch_tc<8, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nf > 2)  return launch_tc<4, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nf > 1)  return launch_tc<2, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
     return launch_tc<1, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
 }
 
@@ -1058,11 +1067,23 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     SawPartial *part = nullptr;
     if (d_scratch && (size_t)SAW_SLOTS * ((nframes + 63) / 64) * sizeof(SawPartial) <= saw_scratch_bytes(nframes))
         part = reinterpret_cast<SawPartial *>(static_cast<char *>(d_scratch) + SAW_SCRATCH_HEADER);
+    static const char *tcc = getenv("SMX_SAW_TC_CAP");                  // tuning overrides
+    static const char *svw = getenv("SMX_SAW_SMALL_VW");
+    static const char *stc = getenv("SMX_SAW_SMALL_TC");
+    const uint32_t tc_cap = tcc ? (uint32_t)atoi(tcc) : 64u;
     if (n_pad >= (1u << 24))
-        return launch_vw<4, true>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, stream);
+        return launch_vw<4, true>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, tc_cap, stream);
     if (n_pad >= (1u << 20))
-        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, stream);
-    return launch_vw<1, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, nullptr, stream);
+        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, tc_cap, stream);
+    // Small banks (< 2^20 voices): 4 voices per lane as well (16-byte loads) and chunks of 16 frames on
+    // blockIdx.y, so that a 64-frame block of 65 536 voices is 64 x 4 workgroups with 64 bus atomics per
+    // frame instead of 128 x 1 with 128: the launch is bound by the same-address atomics at its end
+    // (measured, 64 frames: 2^14 voices 4.0 -> 3.2 us, 2^16 5.7 -> 3.4 us, 2^18 9.2 -> 5.3 us).
+    const uint32_t small_tc = stc ? (uint32_t)atoi(stc) : 16u;
+    const bool small_vw4 = svw ? atoi(svw) == 4 : n_pad >= (1u << 13);
+    if (small_vw4)
+        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, nullptr, small_tc, stream);
+    return launch_vw<1, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, nullptr, small_tc, stream);
 }
 
 int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in, uint32_t *d_or_bus,
