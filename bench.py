@@ -42,7 +42,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-INT_VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 16 int32 lanes/clk/SIMD (measured: profiles/)
+# Vector issue: measured cycles (at 2.4 GHz) one SIMD spends per wave64 instruction at full occupancy
+# (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt): v_add/v_sub/v_ashrrev/v_and/v_xor/v_mov ~2.7,
+# everything VOP3-only or carry-writing (v_add3, v_add_co, v_addc_co, v_mul_lo, v_perm, v_cndmask ...) ~4.5.
+# The kernels' inner loops in those units, per 64 units of work (one wave instruction each lane-op):
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+ISSUE = {"saw_direct": 2.66 + 2.85 + 0.5 * 4.72,      # v_ashrrev + v_add (phase) + half a v_add3 per voice-sample
+         "saw_carry": (4 * 4.46 + 2 * 4.41) / 4,      # 4 v_add_co + 2 v_addc_co per 4 voice-samples (+ scalar popcounts)
+         "pdm_tick_major": 10.0,                      # v_add_co + s_nop 1 + 2 v_writelane, measured as a sequence
+         "pdm_stream": 4.46 + 4.41,                   # v_add_co + v_addc_co
+         "dither_add": 2.85,
+         "pwm2": 2.48 + 2.66 + 2.85 + 2 * 4.72 + 0.75 * 4.28,   # and, sub, add, 2 add3, 3 v_perm per 4 channel-ticks
+         "poly": None}                                # mixed int / fp32 / LDS: see the counters in profiles/
 ALL_LEGS = ("saw_frames", "saw_hi", "c2", "c5", "c3", "c3_streams", "pwm", "c4")
 
 
@@ -175,16 +186,17 @@ def poly_block_numpy(a, nframes):
     return wrap_i32(bus)
 
 
-def roof(alg_bytes, ms, valu_ops=None):
-    """Roofline block of one launch: algorithmic HBM bytes and (optionally) int32 vector lane-ops per launch
-    against the two ceilings; `bound` names the nearer one."""
+def roof(alg_bytes, ms, units=None, issue_cycles=None):
+    """Roofline block of one launch: algorithmic HBM bytes against 8 TB/s, and the issue time of the inner
+    loop's vector instructions (`units` units of work at `issue_cycles` SIMD cycles per 64 of them, all 1024
+    SIMDs busy) as a fraction of the launch; `bound` names the nearer ceiling."""
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     r = {"algorithmic_bytes": float(alg_bytes), "kernel_ms": round(ms, 5), "hbm_GBs": round(gbs, 1),
-         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "int_valu_frac": None, "bound": "hbm"}
-    if valu_ops:
-        r["int_valu_frac"] = round(valu_ops / (ms * 1e-3) / 1e12 / INT_VALU_PEAK_TOPS, 4)
-        if r["int_valu_frac"] > r["hbm_frac"]:
-            r["bound"] = "int-valu issue"
+         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "valu_issue_frac": None, "bound": "hbm"}
+    if units and issue_cycles:
+        r["valu_issue_frac"] = round(units / 64.0 * issue_cycles / SIMD_CYCLES_PER_S / (ms * 1e-3), 4)
+        if r["valu_issue_frac"] > r["hbm_frac"]:
+            r["bound"] = "vector issue"
     return r
 
 
@@ -364,11 +376,11 @@ def settle(step, sync, ms=30.0):
             return
 
 
-def saw_entry(workload, voices, frames, ms, valu_per_vs, extra=None):
+def saw_entry(workload, voices, frames, ms, issue, extra=None):
     vs = voices * frames / (ms * 1e-3)
     e = {"workload": workload, "value": round(vs / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
          "max_voices_48k": int(vs / 48000),
-         "roofline": roof(8.0 * voices + 4.0 * frames, ms, valu_per_vs * voices * frames if valu_per_vs else None),
+         "roofline": roof(8.0 * voices + 4.0 * frames, ms, voices * frames, ISSUE[issue] if issue else None),
          "verified": "bus == closed form"}
     e["hbm_frac"] = e["roofline"]["hbm_frac"]
     if extra:
@@ -394,9 +406,8 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
                     ms = time_saw(big, frames, reps, 5 if frames < 1024 else 1)
                 if verify:
                     big.verify(frames, "saw bank %d frames" % frames, pick=sorted({0, frames // 2, frames - 1}))
-                # vector instructions per voice-sample of the stepping forms (profiles/*insts*): 2.5 direct, 1.5 + 1
-                # scalar in the carry formulation; not defined when the wraps are located instead of stepped
-                valu = None if form == SMX_FORM_AUTO else (1.5 if carry else 2.5)
+                # issue time of the stepping forms' inner loops; not defined when the wraps are located instead
+                valu = None if form == SMX_FORM_AUTO else ("saw_carry" if carry else "saw_direct")
                 out.append(saw_entry(
                     "saw bank, %d voices, %d frames/step%s" % (voices, frames, ", form AUTO (wrap events picked on the device)"
                                                                if form == SMX_FORM_AUTO else ""),
@@ -417,7 +428,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
             big.verify(64, "saw bank, high notes", pick=[0, 31, 63])
         big.bank.set_block_form(SMX_FORM_STEPPING)
         out.append(saw_entry("saw bank, %d voices, 64 frames/step, notes 100..127 only, form AUTO (stepping picked on the device)"
-                             % voices, voices, 64, ms, 1.5))
+                             % voices, voices, 64, ms, "saw_carry"))
     if "c2" in legs:
         # BASELINE config 2: 65 536 voices, 64-frame blocks
         inc, st = synthetic.saw_bank(65536, 0x5EED0002, tab)
@@ -425,7 +436,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         ms = time_saw(b, 64, 200, 20)
         if verify:
             b.verify(64, "c2")
-        out.append(saw_entry("c2: saw bank, 65536 voices, 64 frames/step (BASELINE configs[1] as written)", 65536, 64, ms, 2.5,
+        out.append(saw_entry("c2: saw bank, 65536 voices, 64 frames/step (BASELINE configs[1] as written)", 65536, 64, ms, "saw_direct",
                              {"bound_note": "launch-bound: 512 KiB of state and 0.1 us of arithmetic per launch; the kernel "
                                             "floor of an empty launch is ~2-3 us"}))
         out[-1]["roofline"]["bound"] = "launch latency"
@@ -433,7 +444,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         if verify:
             b.verify(4096, "c2 x 4096 frames", pick=[0, 1, 63, 64, 2047, 4095])
         out.append(saw_entry("c2: saw bank, 65536 voices, 4096 frames/launch (64 JACK blocks per launch, time-parallel chunks)",
-                             65536, 4096, ms, 2.5))
+                             65536, 4096, ms, "saw_direct"))
         b.bank.close()
     if "c5" in legs:
         # BASELINE config 5's per-GPU shard: 8 Mi voices over 8 GPUs = 1 Mi voices each
@@ -444,7 +455,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
             if verify:
                 b.verify(frames, "c5 shard %d frames" % frames)
             out.append(saw_entry("c5 shard: saw bank, 1048576 voices (1/8 of 8 Mi), %d frame(s)/step" % frames,
-                                 1 << 20, frames, ms, 2.5))
+                                 1 << 20, frames, ms, "saw_direct"))
         b.bank.close()
     if "c3" in legs or "c3_streams" in legs:
         # BASELINE config 3: 1 Mi PDM channels (mod_pdm.c integer path), dither 0 and seeded
@@ -483,12 +494,12 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
                         sys.exit("bench.py: PDM CHECK FAILED (%s, dither=%s)" % (layout, with_d))
                     checked = "pulse rows %s == closed form" % rows
                 alg = 12.0 * n + nt * n / 8.0
-                # vector instructions per 64 channel-ticks: 3 (v_add_co + 2 v_writelane) tick-major, 2 channel-stream
                 e = {"workload": "c3: carry-out PDM bank, %d channels, %d ticks/launch, %s layout, dither=%s"
                                  % (n, nt, layout, "seeded" if with_d else "0"),
                      "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
                      "ms_per_step": round(ms, 4),
-                     "roofline": roof(alg, ms, (3.0 if layout == "tick-major" else 2.0) * n * nt + (n * nt if with_d else 0)),
+                     "roofline": roof(alg, ms, n * nt, ISSUE["pdm_tick_major" if layout == "tick-major" else "pdm_stream"]
+                                      + (ISSUE["dither_add"] if with_d else 0.0)),
                      "verified": checked}
                 e["hbm_frac"] = e["roofline"]["hbm_frac"]
                 out.append(e)
@@ -507,7 +518,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         w.close()
         e = {"workload": "noise-shaped PWM bank (pdm2+glide), %d channels, %d ticks/launch, dither seeded" % (n, nt),
              "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
-             "ms_per_step": round(ms, 4), "roofline": roof(52.0 * n + float(nt) * n, ms, 6.06 * n * nt),
+             "ms_per_step": round(ms, 4), "roofline": roof(52.0 * n + float(nt) * n, ms, n * nt, ISSUE["pwm2"]),
              "verified": None}
         e["hbm_frac"] = e["roofline"]["hbm_frac"]
         out.append(e)
@@ -535,7 +546,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         pb.close()
         e = {"workload": "c4: poly bank (saw+LPF+ADSR, stereo; build-defined), %d voices, 64 frames/step" % n,
              "value": round(n * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
-             "roofline": roof(60.0 * n + 64 * 8, ms, 19.0 * n * 64), "verified": checked}
+             "roofline": roof(60.0 * n + 64 * 8, ms, n * 64, ISSUE["poly"]), "verified": checked}
         e["hbm_frac"] = e["roofline"]["hbm_frac"]
         out.append(e)
     return out

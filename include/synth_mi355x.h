@@ -278,6 +278,12 @@ int smx_pwm_load(smx_pwm *p, const struct smx_pwm_arrays *a);
 int smx_pwm_read(smx_pwm *p, const struct smx_pwm_arrays *a);
 int smx_pwm_set_div_count(smx_pwm *p, uint32_t control_div_count);
 uint32_t smx_pwm_div_count(const smx_pwm *p);
+/* The control-rate ISR's beat divider, `struct controlrate` (mod_controlrate.c:19-26, 52-55): every control
+ * tick (a sample tick that starts with control_div_count == 0) runs `if (isr_count % 1024 == 0) beat_pulse++;
+ * isr_count++`; controlrate_poll (:64-72) handles one pending beat per call of the main loop. */
+#define SMX_CONTROLRATE_BEAT_DIV 1024
+int smx_pwm_controlrate(const smx_pwm *p, uint32_t *isr_count, uint32_t *beat_pulse, uint32_t *beat_handled);
+int smx_pwm_controlrate_poll(smx_pwm *p);          /* 1: a beat was handled, 0: none pending */
 /* n_ticks of the ISR (mod_pdm_pwm.c:123-143).  dither: host uint32[n_ticks] or
  * NULL (= 0), shared by all channels of a tick (the firmware masks its
  * generator with 0x3FF, mod_pdm_pwm.c:127).  duty: host uint8[n_ticks *
@@ -386,6 +392,8 @@ int smx_fw_poll(smx_fw *f, uint32_t osc, uint32_t *avg, uint32_t *num,
  * (cproc.h:65-66,73). */
 #define SMX_PROC_ACC   1u                /* out += in              (cproc.h:134-144) */
 #define SMX_PROC_EDGE  2u                /* out = in != last; last = in (cproc.h:146-155) */
+#define SMX_PROC_GPIN  3u                /* out = input word (hw_cproc_stm32f103.h:8-14, the GPIO pin read replaced by an external input word) */
+#define SMX_PROC_GPOUT 4u                /* patcher only: sink (hw_cproc_stm32f103.h:16-22); its input is what smx_patch_tick returns */
 #define SMX_CPROC_INPUT(k) (0x80000000u | (uint32_t)(k))   /* external input word k */
 #define SMX_CPROC_MAX_NODES 32
 struct smx_cproc_node {
@@ -406,6 +414,35 @@ int smx_cproc_tick_n(smx_cproc *c, uint32_t n_ticks, const uint32_t *input, cons
 /* state[node][2][n_instances] = {out, last} */
 int smx_cproc_read_state(smx_cproc *c, uint32_t *state);
 int smx_cproc_load_state(smx_cproc *c, const uint32_t *state);
+
+/* Dynamic patcher: instances allocated one by one and connected by node index, run in allocation order
+ * (stm32f103/mod_bpmodular.c:36-45 struct proc/inst, :72-78 tick, :84-113 apply, :218-228 reset/tick,
+ * :153-190 state get/set).  n_instances copies of the network, one per lane.  Classes: SMX_PROC_ACC,
+ * SMX_PROC_EDGE (cproc.h:134-155), SMX_PROC_GPIN (no input; config = the input word it reads each tick, in
+ * place of the GPIO pin) and SMX_PROC_GPOUT (one input, no state; a sink).  (The reference's own class
+ * table, mod_bpmodular_procs.c, is generated and not in its tree; these four are all the DEF_PROCs it holds.)
+ * The reference answers "bad_ref" / "bad_node" / "alloc_fail" (its bump allocator holds 1024 words, :27;
+ * an instance takes 1 + state fields + inputs of them, :88); here the codes below, and at most
+ * SMX_CPROC_MAX_NODES instances. */
+#define SMX_PATCH_BAD_REF    (-11)
+#define SMX_PATCH_BAD_NODE   (-12)
+#define SMX_PATCH_ALLOC_FAIL (-13)
+typedef struct smx_patch smx_patch;
+smx_patch *smx_patch_create(uint32_t n_instances, uint32_t n_inputs, int device);
+void smx_patch_destroy(smx_patch *p);
+/* class/<cls>/apply: -> node index (>= 0) or one of the codes above; in[]: existing node indices (n_in of
+ * them: acc 1, edge 1, gpin 0, gpout 1); config: the input word of a gpin (< n_inputs), else ignored. */
+int smx_patch_apply(smx_patch *p, uint32_t cls, const uint32_t *in, uint32_t n_in, uint32_t config);
+uint32_t smx_patch_count(const smx_patch *p);
+int smx_patch_reset(smx_patch *p);                      /* patch/reset */
+/* patch/tick, n_ticks times.  input: host uint32[n_ticks][n_inputs][n_instances] (what the gpins read) or
+ * NULL when the patch has no gpin; out: host uint32[n_ticks][n_instances] = what gpout node `gpout` wrote
+ * at each tick, or NULL. */
+int smx_patch_tick(smx_patch *p, uint32_t n_ticks, const uint32_t *input, uint32_t gpout, uint32_t *out);
+/* inst/<node>/state/<field>/get|set for every copy of the network: vals host uint32[n_instances];
+ * field 0 is `out` (acc: out; edge: out, last; gpin: out; gpout: none). */
+int smx_patch_state_get(smx_patch *p, uint32_t node, uint32_t field, uint32_t *vals);
+int smx_patch_state_set(smx_patch *p, uint32_t node, uint32_t field, const uint32_t *vals);
 
 #ifdef __cplusplus
 }

@@ -361,6 +361,7 @@ void orc_cproc_run(const struct orc_cproc_node *nodes, uint32_t n_nodes, uint32_
                 uint32_t *l = &state[((size_t)k * 2 + 1) * n_inst + i];
                 if (nodes[k].proc == ORC_PROC_ACC) orc_acc_update(o, in);
                 else if (nodes[k].proc == ORC_PROC_EDGE) orc_edge_update(o, l, in);
+                else if (nodes[k].proc == ORC_PROC_GPIN) *o = in;   /* hw_cproc_stm32f103.h:12-14, the pin = an input word */
             }
             if (out) out[(size_t)t * n_inst + i] = state[((size_t)out_node * 2) * n_inst + i];
         }

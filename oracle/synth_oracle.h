@@ -135,7 +135,7 @@ void orc_edge_update(uint32_t *out, uint32_t *last, uint32_t in);    /* :152-155
  * runs only when (g[t] & cond) != 0.  input[t][n_inputs][n_inst], out[t][n_inst] = the
  * `out` of node out_node after tick t.  state[node][2][n_inst] = {out, last}. */
 #define ORC_CPROC_INPUT 0x80000000u
-enum { ORC_PROC_ACC = 1, ORC_PROC_EDGE = 2 };
+enum { ORC_PROC_ACC = 1, ORC_PROC_EDGE = 2, ORC_PROC_GPIN = 3 };
 struct orc_cproc_node { uint32_t proc, in, cond; };
 void orc_cproc_run(const struct orc_cproc_node *nodes, uint32_t n_nodes, uint32_t n_inst,
                    uint32_t n_inputs, uint32_t *state, const uint32_t *input,

@@ -56,7 +56,7 @@ class CprocNode(C.Structure):        # struct smx_cproc_node
     _fields_ = [("proc", C.c_uint32), ("inp", C.c_uint32), ("cond", C.c_uint32)]
 
 
-PROC_ACC, PROC_EDGE = 1, 2
+PROC_ACC, PROC_EDGE, PROC_GPIN, PROC_GPOUT = 1, 2, 3, 4
 
 
 def cproc_input(k):
@@ -144,6 +144,8 @@ ABI = [
     ("smx_pwm_read", C.c_int, [_P, C.POINTER(PwmArrays)]),
     ("smx_pwm_set_div_count", C.c_int, [_P, C.c_uint32]),
     ("smx_pwm_div_count", C.c_uint32, [_P]),
+    ("smx_pwm_controlrate", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("smx_pwm_controlrate_poll", C.c_int, [_P]),
     ("smx_pwm_tick_n", C.c_int, [_P, C.c_uint32, _P, _P]),
     ("smx_pwm_tick_n_async", C.c_int, [_P, C.c_uint32, C.c_int]),
     ("smx_pwm_dither_dev", _P, [_P, C.c_uint32]),
@@ -170,6 +172,14 @@ ABI = [
     ("smx_cproc_tick_n", C.c_int, [_P, C.c_uint32, _P, _P, C.c_uint32, _P]),
     ("smx_cproc_read_state", C.c_int, [_P, _P]),
     ("smx_cproc_load_state", C.c_int, [_P, _P]),
+    ("smx_patch_create", _P, [C.c_uint32, C.c_uint32, C.c_int]),
+    ("smx_patch_destroy", None, [_P]),
+    ("smx_patch_apply", C.c_int, [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32]),
+    ("smx_patch_count", C.c_uint32, [_P]),
+    ("smx_patch_reset", C.c_int, [_P]),
+    ("smx_patch_tick", C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P]),
+    ("smx_patch_state_get", C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    ("smx_patch_state_set", C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     ("smx_fw_create", _P, [C.c_uint32, C.c_uint32, C.c_int]),
     ("smx_fw_destroy", None, [_P]),
     ("smx_fw_pwm", _P, [_P]),
@@ -498,6 +508,15 @@ class PwmBank:
     def div_count(self, c):
         _check(lib().smx_pwm_set_div_count(self._h, c), "smx_pwm_set_div_count")
 
+    def controlrate(self):
+        """struct controlrate (mod_controlrate.c:21-26): (isr_count, beat_pulse, beat_handled)."""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().smx_pwm_controlrate(self._h, C.byref(a), C.byref(b), C.byref(c)), "smx_pwm_controlrate")
+        return a.value, b.value, c.value
+
+    def controlrate_poll(self):
+        return lib().smx_pwm_controlrate_poll(self._h)
+
     def tick_n(self, n_ticks, dither=None, want_duty=True):
         d = None if dither is None else np.ascontiguousarray(dither, np.uint32)
         duty = np.empty((n_ticks, self.n), np.uint8) if want_duty else None
@@ -575,6 +594,55 @@ class OscBank:
         st = PmeasArrays(**{k: v.ctypes.data for k, v in out.items()})
         _check(lib().smx_osc_read_pmeas(self._h, C.byref(st)), "smx_osc_read_pmeas")
         return out
+
+
+PATCH_BAD_REF, PATCH_BAD_NODE, PATCH_ALLOC_FAIL = -11, -12, -13
+
+
+class Patch:
+    """Dynamic patcher (stm32f103/mod_bpmodular.c): instances allocated one by one, connected by node
+    index, run in allocation order; n copies of the network."""
+
+    def __init__(self, n_instances, n_inputs=0, device=0):
+        self._h = lib().smx_patch_create(n_instances, n_inputs, device)
+        if not self._h:
+            raise SmxError("smx_patch_create: " + lib().smx_last_error().decode())
+        self.n, self.n_inputs = n_instances, n_inputs
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.smx_patch_destroy(self._h)
+        self._h = None
+
+    __del__ = close
+
+    def apply(self, cls, inputs=(), config=0):
+        """-> node index, or a negative PATCH_* code."""
+        a = np.ascontiguousarray(inputs, np.uint32)
+        return lib().smx_patch_apply(self._h, cls, _ptr(a) if len(a) else None, len(a), config)
+
+    def count(self):
+        return lib().smx_patch_count(self._h)
+
+    def reset(self):
+        _check(lib().smx_patch_reset(self._h), "smx_patch_reset")
+
+    def tick(self, n=1, inputs=None, gpout=None):
+        """inputs: uint32[n, n_inputs, n_instances]; -> uint32[n, n_instances] written by node `gpout`, or None."""
+        inp = None if inputs is None else np.ascontiguousarray(inputs, np.uint32)
+        assert inp is None or inp.shape == (n, self.n_inputs, self.n)
+        out = None if gpout is None else np.empty((n, self.n), np.uint32)
+        _check(lib().smx_patch_tick(self._h, n, _ptr(inp), 0 if gpout is None else gpout, _ptr(out)), "smx_patch_tick")
+        return out
+
+    def state_get(self, node, field):
+        v = np.empty(self.n, np.uint32)
+        rv = lib().smx_patch_state_get(self._h, node, field, _ptr(v))
+        return v if rv == 0 else rv
+
+    def state_set(self, node, field, vals):
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(vals, np.uint32), (self.n,)), np.uint32)
+        return lib().smx_patch_state_set(self._h, node, field, _ptr(v))
 
 
 def tag_u32_packet(args, payload=b"", frm=()):

@@ -9,6 +9,8 @@ struct smx_pwm {
     uint32_t n = 0, n_pad = 0;
     int order = 2, device = 0;
     uint32_t div_log = 12, out_shift = 24, div_count = 0;
+    // struct controlrate (mod_controlrate.c:21-26): counts control ticks; a beat every 1024 of them
+    uint32_t isr_count = 0, beat_pulse = 0, beat_handled = 0;
     smx::PwmArrays d{};
     uint32_t *d_dither = nullptr; uint32_t dither_cap = 0;
     uint8_t *d_duty = nullptr; size_t duty_cap = 0;
@@ -115,6 +117,24 @@ extern "C" int smx_pwm_set_div_count(smx_pwm *p, uint32_t c)
 }
 extern "C" uint32_t smx_pwm_div_count(const smx_pwm *p) { return p ? p->div_count : 0; }
 
+// struct controlrate (mod_controlrate.c:21-26)
+extern "C" int smx_pwm_controlrate(const smx_pwm *p, uint32_t *isr_count, uint32_t *beat_pulse, uint32_t *beat_handled)
+{
+    if (!p) return SMX_E_ARG;
+    if (isr_count) *isr_count = p->isr_count;
+    if (beat_pulse) *beat_pulse = p->beat_pulse;
+    if (beat_handled) *beat_handled = p->beat_handled;
+    return SMX_OK;
+}
+// controlrate_poll / controlrate_beat_poll (mod_controlrate.c:64-72): the main loop handles one pending
+// beat per call.  Returns 1 if a beat was handled, 0 if none was pending.
+extern "C" int smx_pwm_controlrate_poll(smx_pwm *p)
+{
+    if (!p) return SMX_E_ARG;
+    if (p->beat_handled != p->beat_pulse) { p->beat_handled++; return 1; }
+    return 0;
+}
+
 // pdm_init, mod_pdm_pwm.c:147-160
 extern "C" int smx_pwm_init(smx_pwm *p)
 {
@@ -124,6 +144,7 @@ extern "C" int smx_pwm_init(smx_pwm *p)
     struct smx_pwm_arrays a = {sp.data(), z.data(), z.data(), z.data(), z.data(),
                                {z.data(), z.data(), z.data(), z.data()}};
     p->div_count = 0;
+    p->isr_count = p->beat_pulse = p->beat_handled = 0;
     return smx_pwm_load(p, &a);
 }
 
@@ -174,6 +195,18 @@ extern "C" int smx_pwm_tick_n_async(smx_pwm *p, uint32_t n_ticks, int with_dithe
     rv = smx::launch_pwm_bank(p->d, p->order, with_dither ? p->d_dither : nullptr, p->d_duty, p->n_pad,
                               n_ticks, p->div_count, p->div_log, p->out_shift, p->stream);
     if (rv) return rv;
+    {   // control_update's beat divider (mod_controlrate.c:52-55): every control tick of this run --
+        // a sample tick that starts with control_div_count == 0 (mod_pdm_pwm.c:129-137) -- does
+        // `if (isr_count % 1024 == 0) beat_pulse++; isr_count++`
+        const uint32_t div = 1u << p->div_log;
+        const uint32_t first = (div - p->div_count) & (div - 1);            // offset of the run's first control tick
+        const uint32_t k = first < n_ticks ? 1u + (n_ticks - 1u - first) / div : 0u;
+        // multiples of 1024 in [isr_count, isr_count + k), isr_count being a 32-bit wrapping counter
+        const uint64_t a = p->isr_count, b = a + k;
+        p->beat_pulse += (uint32_t)((b + SMX_CONTROLRATE_BEAT_DIV - 1) / SMX_CONTROLRATE_BEAT_DIV -
+                                    (a + SMX_CONTROLRATE_BEAT_DIV - 1) / SMX_CONTROLRATE_BEAT_DIV);
+        p->isr_count = (uint32_t)b;
+    }
     p->div_count = (uint32_t)(((uint64_t)p->div_count + n_ticks) & ((1u << p->div_log) - 1));
     return SMX_OK;
 }

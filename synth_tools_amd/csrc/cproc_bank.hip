@@ -56,6 +56,8 @@ void cproc_kernel(smx::CprocProgram prog, uint32_t *__restrict__ state,   // [no
             uint32_t *l = &lds[(k * 2 + 1) * 256 + tid];
             if (nd.proc == 1) {                                 // acc, cproc.h:142-144
                 *o += in;
+            } else if (nd.proc == 3) {                          // gpin, hw_cproc_stm32f103.h:12-14: out = the input word
+                *o = in;
             } else {                                            // edge, cproc.h:152-155
                 *o = (in != *l);
                 *l = in;

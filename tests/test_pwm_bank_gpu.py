@@ -108,3 +108,43 @@ def test_full_size_properties_256k_channels(smx, orc):
     orc.orc_pwm_bank_run(C.byref(ob), None, nt, want.ctypes.data)
     assert np.array_equal(duty[:, sl], want)
     bank.close()
+
+
+def test_controlrate_beat_divider(smx):
+    """control_update's beat divider (mod_controlrate.c:19, 52-55): `if (isr_count % 1024 == 0) beat_pulse++;
+    isr_count++` once per control tick, a control tick being a sample tick that starts with
+    control_div_count == 0 (mod_pdm_pwm.c:129-137); controlrate_poll handles one beat per call (:64-72).
+    Ragged runs over more than 2 x 1024 control ticks against the statement above."""
+    div_log = 2
+    bank = smx.PwmBank(96, order=2, control_div_log=div_log)
+    bank.init()
+    assert bank.controlrate() == (0, 0, 0)
+    rng = np.random.default_rng(5)
+    div_count, isr, beat = 0, 0, 0
+    handled = 0
+    total = 0
+    while isr < 2 * 1024 + 300:
+        n = int(rng.choice([1, 2, 3, 4, 5, 64, 257, 1000]))
+        for _ in range(n):
+            if div_count == 0:
+                if isr % 1024 == 0:
+                    beat += 1
+                isr += 1
+            div_count = (div_count + 1) % (1 << div_log)
+        bank.tick_n(n, want_duty=False)
+        total += n
+        assert bank.div_count == div_count
+        got = bank.controlrate()
+        assert got[:2] == (isr, beat), (total, got)
+        if rng.random() < 0.3 and handled < beat:
+            assert bank.controlrate_poll() == 1
+            handled += 1
+            assert bank.controlrate()[2] == handled
+    assert beat == 3
+    while handled < beat:
+        assert bank.controlrate_poll() == 1
+        handled += 1
+    assert bank.controlrate_poll() == 0 and bank.controlrate() == (isr, beat, beat)
+    bank.init()
+    assert bank.controlrate() == (0, 0, 0)
+    bank.close()
