@@ -119,7 +119,8 @@ def test_dynamic_patcher(smx, orc):
             classes.append(cls)
             srcs.append(src)
         assert p.count() == len(classes) and gpouts
-        assert p.apply(PROC_ACC, [gpouts[0]]) == PATCH_BAD_NODE     # a gpout has no state to read
+        # a gpout has no state to read; as in the reference the allocation is tried first (:89-94, then :102-106)
+        assert p.apply(PROC_ACC, [gpouts[0]]) == (PATCH_ALLOC_FAIL if len(kernel_nodes) == 32 else PATCH_BAD_NODE)
         state = np.zeros((len(kernel_nodes), 2, n), np.uint32)
         # poke some state from outside (inst/<n>/state/<k>/set)
         for node in rng.choice(len(classes), 5, replace=False):
