@@ -547,6 +547,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         e = {"workload": "c4: poly bank (saw+LPF+ADSR, stereo; build-defined), %d voices, 64 frames/step" % n,
              "value": round(n * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
              "roofline": roof(60.0 * n + 64 * 8, ms, n * 64, ISSUE["poly"]), "verified": checked}
+        e["roofline"]["bound"] = "vector issue + LDS atomics (19 mixed int/fp32 instructions per voice-sample; profiles/r02_counters.json)"
         e["hbm_frac"] = e["roofline"]["hbm_frac"]
         out.append(e)
     return out

@@ -173,7 +173,8 @@ int smx_bank_comm_ranks(const smx_bank *b);
  * reduce and the copy to the host run on the second stream behind the kernel, so the caller
  * waits for neither. */
 int smx_bank_allreduce_async(smx_bank *b, int n);
-/* Blocks per collective, 1..8 (1: every block's sum is issued at once). */
+/* Blocks per collective, 1..16; default 8 (1: every block's sum is issued at once).  A group hides the
+ * collective's latency L behind `blocks` kernels: it pays when blocks x (kernel time) >= L. */
 int smx_bank_set_comm_group(smx_bank *b, int blocks);
 /* Counters: collectives issued so far and the block sums they carried. */
 int smx_bank_comm_stats(const smx_bank *b, unsigned long long *collectives, unsigned long long *block_sums);

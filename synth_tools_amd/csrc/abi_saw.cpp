@@ -96,7 +96,7 @@ struct smx_bank {
     // ONE all-reduce over a contiguous range instead of one collective per block (xGMI is
     // latency-bound at these sizes; the frames between a block's end and the stride are
     // summed along and ignored).
-    static constexpr int NBUS = 16;
+    static constexpr int NBUS = 32;
     int32_t *d_ring = nullptr;
     int32_t *d_bus[NBUS] = {};                   // d_ring + i * bus_cap
     uint32_t bus_zeroed[NBUS] = {};              // leading frames known to be zero
@@ -134,7 +134,7 @@ struct smx_bank {
     int ar_queue[NBUS] = {};                     // bus indices with a requested, not yet issued sum
     int ar_frames[NBUS] = {};
     int ar_count = 0;
-    int comm_group = NBUS / 2;                   // blocks per collective (smx_bank_set_comm_group)
+    int comm_group = 8;                          // blocks per collective (smx_bank_set_comm_group, 1 .. NBUS/2)
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int comm_count = 0;                          // ncclCommCount: ranks the communicator really spans
