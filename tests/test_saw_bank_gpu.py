@@ -502,3 +502,12 @@ def test_billion_voice_bank_index_safety(smx):
     want = state + np.uint32(64) * inc                    # inc == 0: unchanged
     assert np.array_equal(gst, want)
     bank.close()
+
+
+@pytest.mark.parametrize("n", [4097, 8192, 8193, 12288, 65536 + 1024, (1 << 18) + 5])
+def test_small_bank_chunk_edges(smx, orc, inc_table, n):
+    """Banks below 2^20 voices cut blocks into 16-frame chunks on blockIdx.y (1 voice per lane below 2^13
+    padded voices, 4 from there on): every chunk boundary, ragged last chunks, and the lazily materialised phase
+    (tbase != 0) across them."""
+    inc, state = synthetic.saw_bank(n, 0x5EED0600 + n, inc_table, active_fraction=0.85)
+    _check(smx, orc, inc, state, [15, 16, 17, 1, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 5, 257])
