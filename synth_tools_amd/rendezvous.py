@@ -63,6 +63,10 @@ class Rendezvous:
         os.makedirs(self.dir, exist_ok=True)
         port_file = os.path.join(self.dir, "port")
         if rank == 0:
+            try:
+                os.unlink(port_file)                   # a file left by a run that died (same directory name)
+            except OSError:
+                pass
             ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             ls.bind((self.addr, 0))
@@ -78,10 +82,14 @@ class Rendezvous:
                     c, _ = ls.accept()
                     c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     c.settimeout(timeout)
-                    (r,) = struct.unpack("<I", _recv_exact(c, 4))
-                    if r <= 0 or r >= world or r in self._peers:
-                        c.close()
-                        raise RendezvousError("rendezvous: unexpected rank %d" % r)
+                    try:
+                        magic, r = struct.unpack("<4sI", _recv_exact(c, 8))
+                    except (RendezvousError, OSError):
+                        magic, r = b"", 0
+                    if magic != b"SMX1" or r <= 0 or r >= world or r in self._peers:
+                        c.close()                      # not one of ours (or a duplicate): keep listening
+                        continue
+                    c.sendall(b"SMX1")
                     self._peers[r] = c
             except socket.timeout:
                 raise RendezvousError("rendezvous: %d of %d ranks arrived within %.0f s"
@@ -99,10 +107,12 @@ class Rendezvous:
                     s = socket.create_connection((self.addr, port), timeout=2.0)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     s.settimeout(timeout)
-                    s.sendall(struct.pack("<I", rank))
+                    s.sendall(struct.pack("<4sI", b"SMX1", rank))
+                    if _recv_exact(s, 4) != b"SMX1":               # whoever listens there is not rank 0
+                        raise OSError("not a rendezvous server")
                     self._sock = s
                     break
-                except (OSError, ValueError, IndexError) as e:     # not published yet / stale file
+                except (OSError, ValueError, IndexError, RendezvousError) as e:   # not published yet / stale file
                     last_err = e
                     time.sleep(0.02)
 
