@@ -398,23 +398,23 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         # longer blocks of the same bank; 64 frames = the JACK operating point (linux/jack_midi.c:19-20)
         for frames in (8, 16, 32, 64, 1024):
             carry = frames > 16 and voices * frames >= 1 << 30
-            for form in ((SMX_FORM_STEPPING, SMX_FORM_AUTO) if (carry and frames > 32) else (SMX_FORM_STEPPING,)):
+            # blocks of more than 32 frames have two exact forms: AUTO (default) lets the device pick from the bank's
+            # increments, STEPPING is the data-independent one (also what AUTO falls back to: DESIGN 3.2b)
+            for form in ((SMX_FORM_AUTO, SMX_FORM_STEPPING) if (carry and frames > 32) else (SMX_FORM_AUTO,)):
                 big.bank.set_block_form(form)
                 reps = 50 if frames < 1024 else 5
                 ms = time_saw(big, frames, reps, 5 if frames < 1024 else 1)
-                if form == SMX_FORM_AUTO:          # a few launches until the device-side statistic has settled
-                    ms = time_saw(big, frames, reps, 5 if frames < 1024 else 1)
                 if verify:
                     big.verify(frames, "saw bank %d frames" % frames, pick=sorted({0, frames // 2, frames - 1}))
+                events = carry and frames > 32 and form == SMX_FORM_AUTO
                 # issue time of the stepping forms' inner loops; not defined when the wraps are located instead
-                valu = None if form == SMX_FORM_AUTO else ("saw_carry" if carry else "saw_direct")
+                valu = None if events else ("saw_carry" if carry else "saw_direct")
                 out.append(saw_entry(
-                    "saw bank, %d voices, %d frames/step%s" % (voices, frames, ", form AUTO (wrap events picked on the device)"
-                                                               if form == SMX_FORM_AUTO else ""),
+                    "saw bank, %d voices, %d frames/step%s" % (voices, frames, ", form STEPPING pinned" if form == SMX_FORM_STEPPING else ""),
                     voices, frames, ms, valu,
-                    {"formulation": ("carry, wrap events (AUTO)" if form == SMX_FORM_AUTO else "carry, stepping (default: "
-                                     "data-independent run time)") if carry else "direct"}))
-        big.bank.set_block_form(SMX_FORM_STEPPING)
+                    {"formulation": ("carry, wrap events (AUTO: picked on the device from the bank's increments)" if events
+                                     else "carry, stepping") if carry else "direct"}))
+        big.bank.set_block_form(SMX_FORM_AUTO)
     if "saw_hi" in legs:
         # the same 64-frame blocks on a bank of high voices only (MIDI notes 100..127: 3..17 wraps per voice per
         # block): AUTO keeps the stepping form there, whose time does not depend on the data
@@ -422,12 +422,10 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         hi_inc = np.ascontiguousarray(tab[100 + (r % np.uint64(28)).astype(np.int64)].astype(np.uint32))
         big.bank.load(inc=hi_inc)
         big.rebase()
-        big.bank.set_block_form(SMX_FORM_AUTO)
         ms = time_saw(big, 64, 50, 5)
         if verify:
             big.verify(64, "saw bank, high notes", pick=[0, 31, 63])
-        big.bank.set_block_form(SMX_FORM_STEPPING)
-        out.append(saw_entry("saw bank, %d voices, 64 frames/step, notes 100..127 only, form AUTO (stepping picked on the device)"
+        out.append(saw_entry("saw bank, %d voices, 64 frames/step, notes 100..127 only (AUTO keeps the stepping form here)"
                              % voices, voices, 64, ms, "saw_carry"))
     if "c2" in legs:
         # BASELINE config 2: 65 536 voices, 64-frame blocks

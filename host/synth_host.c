@@ -177,7 +177,7 @@ int main(int argc, char **argv) {
         audio_out = FAKE_AUDIO_PORT;
         if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
         if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
-        if (bank && getenv("SYNTH_FORM_AUTO")) ASSERT(0 == smx_bank_set_block_form(bank, SMX_FORM_AUTO));
+        if (bank && getenv("SYNTH_FORM_STEPPING")) ASSERT(0 == smx_bank_set_block_form(bank, SMX_FORM_STEPPING));
         if (bank && getenv("SYNTH_FILL")) bank_fill(bank, (uint32_t)voices);
         synth_init(&synth);
         FILE *out = fopen(argv[5], "wb");
@@ -229,7 +229,7 @@ int main(int argc, char **argv) {
         ASSERT(audio_out = jack.port_register(client, "audio_out", JACK_DEFAULT_AUDIO_TYPE, JackPortIsOutput, 0));
         if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
         if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
-        if (bank && getenv("SYNTH_FORM_AUTO")) ASSERT(0 == smx_bank_set_block_form(bank, SMX_FORM_AUTO));
+        if (bank && getenv("SYNTH_FORM_STEPPING")) ASSERT(0 == smx_bank_set_block_form(bank, SMX_FORM_STEPPING));
         if (bank && getenv("SYNTH_FILL")) bank_fill(bank, (uint32_t)voices);
         synth_init(&synth);
         jack.set_process_callback(client, process, 0);

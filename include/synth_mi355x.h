@@ -126,16 +126,20 @@ int smx_bank_set_block_mode(smx_bank *b, int mode);
  * (linux/synth.c:172-179); every form gives the same bits.  STEPPING adds inc frame by frame and
  * counts the carry-outs.  EVENTS locates each wrap directly (first at floor(~phase/inc), then every
  * floor((2^32-1)/inc) or one more frames): much less work for banks of mostly low voices, more for
- * banks of high ones, so its run time depends on the data (up to 3x the stepping form on a bank of
- * only very high notes).  STEPPING is the default: a real-time caller (the JACK process callback,
- * linux/synth.c:277-282) gets a run time that does not depend on what is being played.  AUTO keeps a
- * statistic of the increments on the device and picks per launch (largest increment below MIDI note
- * ~110 and a mean of at most 2 wraps per voice and 64 frames: events; otherwise stepping); the first
- * long block after smx_bank_load(inc) steps. */
+ * banks of high ones (up to 3x the stepping form on a bank of only very high notes).  AUTO (default) keeps
+ * a statistic of the increments on the device and picks per launch: events only while the largest increment
+ * is below MIDI note ~110 and the mean is at most 2 wraps per voice and 64 frames.  The statistic is exact as
+ * of the last long block and is kept conservative by every note event in between (a new increment or a
+ * running sum above the bound selects stepping at once), so the event form never runs on a bank outside
+ * the rule: on every bank the rule admits it was measured at most as slow as stepping -- a
+ * real-time caller (the JACK process callback, linux/synth.c:277-282) gets at most the stepping form's time.
+ * The first long block after smx_bank_load(inc) steps.  STEPPING / EVENTS pin a form. */
 #define SMX_FORM_AUTO     0
 #define SMX_FORM_STEPPING 1
 #define SMX_FORM_EVENTS   2
 int smx_bank_set_block_form(smx_bank *b, int form);
+/* The form the next long block will run (SMX_FORM_STEPPING / SMX_FORM_EVENTS); synchronises. */
+int smx_bank_next_block_form(smx_bank *b);
 
 /* Asynchronous form: enqueue one block of n frames on the bank's stream and
  * leave the int32 bus in device memory (smx_bank_bus_dev).  No host sync. */

@@ -96,6 +96,7 @@ ABI = [
     ("smx_bank_run", C.c_int, [_P, _P, _P, C.c_int]),
     ("smx_bank_set_block_mode", C.c_int, [_P, C.c_int]),
     ("smx_bank_set_block_form", C.c_int, [_P, C.c_int]),
+    ("smx_bank_next_block_form", C.c_int, [_P]),
     ("smx_bank_run_async", C.c_int, [_P, C.c_int]),
     ("smx_bank_bus_dev", _P, [_P]),
     ("smx_bank_sync", C.c_int, [_P]),
@@ -263,6 +264,9 @@ class SawBank:
     def set_block_form(self, form):
         """0 auto, 1 stepping, 2 wrap events (long blocks of big banks; same bits either way)."""
         _check(lib().smx_bank_set_block_form(self._h, form), "smx_bank_set_block_form")
+
+    def next_block_form(self):
+        return lib().smx_bank_next_block_form(self._h)
 
     def midi_event(self, msg):
         m = np.ascontiguousarray(msg, np.uint8)

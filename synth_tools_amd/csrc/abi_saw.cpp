@@ -107,13 +107,14 @@ struct smx_bank {
     // pipelined block mode (smx_bank_set_block_mode): the bus of block k is copied to pinned
     // memory behind its kernel and handed out by the call that launches block k+1
     int block_mode = 0;
-    int block_form = SMX_FORM_STEPPING;          // smx_bank_set_block_form (default: data-independent run time)
+    int block_form = SMX_FORM_AUTO;              // smx_bank_set_block_form
     // AUTO: the device picks the form per launch and both forms are queued (the loser returns at
-    // once, ~3 us).  The finalize kernel also writes its pick to this pinned word; once the host
-    // has seen the same pick at FORM_STABLE consecutive launches it queues only that form (both
-    // are exact on any bank, so a stale pick costs time, never bits).
+    // once, ~3 us).  The finalize kernel also writes {its pick, the number of long blocks finalized}
+    // to these two pinned words; once the host has seen the same pick from FORM_STABLE consecutive
+    // NEW long blocks, with no note event since, it queues only that form (both are exact on any
+    // bank, so a stale pick would cost time, never bits -- and a note event un-pins at once).
     uint32_t *h_form = nullptr;
-    uint32_t form_seen = 0xFFFFFFFFu;
+    uint32_t form_seen = 0xFFFFFFFFu, form_seq = 0;
     int form_stable = 0;
     static constexpr int FORM_STABLE = 4;
     int32_t *h_pipe[2] = {nullptr, nullptr};
@@ -153,6 +154,13 @@ struct smx_bank {
 };
 
 static int bank_comm_flush(smx_bank *b);
+
+// The increments changed (load / note event): what the host has seen of the device's picks is void.
+static void bank_form_unpin(smx_bank *b)
+{
+    b->form_seen = 0xFFFFFFFFu;
+    b->form_stable = 0;
+}
 
 static int bank_ensure_bus(smx_bank *b, uint32_t n)
 {
@@ -215,7 +223,8 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     if ((e = hipMalloc((void **)&b->d_state0, bytes)) != hipSuccess) return fail("hipMalloc state", e);
     if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
     if ((e = hipHostMalloc((void **)&b->h_form, 64, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
-    *b->h_form = 0xFFFFFFFFu;
+    b->h_form[0] = 0xFFFFFFFFu;
+    b->h_form[1] = 0;
     if ((e = hipEventCreate(&b->ev_t0)) != hipSuccess) return fail("event", e);
     if ((e = hipEventCreate(&b->ev_t1)) != hipSuccess) return fail("event", e);
     for (int i = 0; i < smx_bank::NBUS; i++) {
@@ -291,9 +300,7 @@ extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *s
         // new increments: the statistic that picks the long-block form is void (stepping until the
         // next long block has measured the new bank)
         if (b->d_scratch) SMX_HIP(hipMemsetAsync(b->d_scratch, 0, smx::saw_scratch_header_bytes(), b->stream));
-        if (b->h_form) *(volatile uint32_t *)b->h_form = 0xFFFFFFFFu;
-        b->form_seen = 0xFFFFFFFFu;
-        b->form_stable = 0;
+        bank_form_unpin(b);
     }
     if (state)
         SMX_HIP(hipMemcpy(b->d_state0, state, (size_t)b->n * 4, hipMemcpyHostToDevice));
@@ -336,8 +343,9 @@ extern "C" int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state)
 static int bank_set_inc(smx_bank *b, uint32_t v, uint32_t inc)
 {
     SMX_HIP(hipSetDevice(b->device));
-    int rv = smx::launch_saw_rebase(b->d_inc, b->d_state0, v, inc, b->elapsed, b->stream);
+    int rv = smx::launch_saw_rebase(b->d_inc, b->d_state0, v, inc, b->elapsed, b->d_scratch, b->n_pad, b->stream);
     if (rv) return rv;
+    bank_form_unpin(b);
     b->free_map.set_free(v, inc == 0);
     return SMX_OK;
 }
@@ -475,9 +483,14 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
     if (rv) return rv;
     int form = b->block_form;
     if (form == SMX_FORM_AUTO && n > 32 && b->h_form) {
-        const uint32_t seen = *(volatile uint32_t *)b->h_form;          // whatever has landed: no sync
-        if (seen == b->form_seen) b->form_stable++; else { b->form_seen = seen; b->form_stable = 0; }
-        if (b->form_stable >= smx_bank::FORM_STABLE && seen <= 1u) form = seen ? SMX_FORM_EVENTS : SMX_FORM_STEPPING;
+        const volatile uint32_t *hf = b->h_form;                         // whatever has landed: no sync
+        const uint32_t seq = hf[1], seen = hf[0];
+        if (seq != b->form_seq) {                                        // a long block was finalized since the last look
+            b->form_seq = seq;
+            if (seen == b->form_seen) b->form_stable++; else { b->form_seen = seen; b->form_stable = 0; }
+        }
+        if (b->form_stable >= smx_bank::FORM_STABLE && b->form_seen <= 1u)
+            form = b->form_seen ? SMX_FORM_EVENTS : SMX_FORM_STEPPING;
     }
     rv = smx::launch_saw_bank(b->d_inc, b->d_state0, b->d_bus[bi], b->d_bus[bnext], b->n_pad, (uint32_t)n,
                               b->elapsed, b->d_scratch, form, b->h_form, b->stream);
@@ -563,7 +576,8 @@ extern "C" int smx_bank_midi_events(smx_bank *b, const uint8_t *msgs3, size_t n_
     SMX_HIP(hipEventRecord(b->ev_stage[k], b->stream));
     b->ev_stage_busy[k] = true;
     b->ev_k ^= 1;
-    return smx::launch_saw_rebase_batch(b->d_inc, b->d_state0, b->d_ev, npairs, b->elapsed, b->stream);
+    bank_form_unpin(b);
+    return smx::launch_saw_rebase_batch(b->d_inc, b->d_state0, b->d_ev, npairs, b->elapsed, b->d_scratch, b->n_pad, b->stream);
 }
 
 extern "C" int smx_bank_sync(smx_bank *b)
@@ -607,6 +621,19 @@ extern "C" int smx_bank_set_block_form(smx_bank *b, int form)
     }
     b->block_form = form;
     return SMX_OK;
+}
+
+// Which form would the next long block of an AUTO bank run?  (Synchronises; for tests and tools.)
+extern "C" int smx_bank_next_block_form(smx_bank *b)
+{
+    if (!b) return SMX_E_ARG;
+    if (b->block_form != SMX_FORM_AUTO) return b->block_form;
+    if (!b->d_scratch) return SMX_FORM_STEPPING;
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    uint32_t pick = 0;
+    SMX_HIP(hipMemcpy(&pick, b->d_scratch, 4, hipMemcpyDeviceToHost));
+    return pick ? SMX_FORM_EVENTS : SMX_FORM_STEPPING;
 }
 
 extern "C" int smx_bank_set_block_mode(smx_bank *b, int mode)

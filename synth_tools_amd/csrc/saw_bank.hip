@@ -74,10 +74,18 @@ struct SawPartial {
     uint32_t W[64];               // carries out of the phase add at frame t (t -> t+1)
     uint32_t maxinc, pad_;        // largest increment seen (statistic for the next launch's formulation)
 };
-// The first bytes of the scratch area: which form of the carry kernel the next long-block launch
-// runs (0: stepping, 1: wrap events).  Written by the finalize kernel from the bank's statistics,
-// read by both forms at their start -- the one that is not selected returns at once.  Both forms
-// are exact for any bank; the flag only steers speed, so a stale value is harmless.
+// The first bytes of the scratch area (uint32 words):
+//   [0] form of the next long-block launch under AUTO (0: stepping, 1: wrap events), read by both forms at
+//       their start -- the one that is not selected returns at once;
+//   [1] which slot layout the launch filled (for the finalize kernel);
+//   [2] number of long blocks finalized so far (copied to the host's mirror: tells a fresh pick from an old one);
+//   [4..5] exact sum of all increments as of the last long block, kept current by the note-event kernels.
+// The finalize kernel writes [0] from the launch's own statistics (largest increment, sum of increments).
+// Note events keep it CONSERVATIVE in between: a new increment above the bound, or a running sum above the
+// bound, clears [0] at once (saw_stats_note), so that the event form never runs on a bank the rule would not
+// admit -- that is what bounds AUTO's run time.  Both forms are exact for any bank; the flag
+// only steers speed.
+constexpr uint32_t SAW_EVENTS_MAX_INC = 13u << 25;          // 6.5 wraps per 64 frames (MIDI note 110 at 48 kHz)
 constexpr size_t SAW_SCRATCH_HEADER = 64;
 
 // SLOT: instead of one atomic per frame per workgroup on the bus itself (same-address integer
@@ -635,6 +643,26 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
     if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicAdd(&out->I, S[1]); atomicMax(&out->maxinc, MX); }
 }
 
+// End of a long block: the exact statistics of this launch (header words above) and the host's mirror
+// {pick, number of long blocks finalized}.
+__device__ __forceinline__ void saw_stats_publish(uint32_t *__restrict__ hdr, uint32_t *__restrict__ host_flag,
+                                                  uint32_t pick, unsigned long long sum_inc)
+{
+    hdr[0] = pick;
+    const uint32_t seq = hdr[2] + 1u;
+    hdr[2] = seq;
+    *reinterpret_cast<unsigned long long *>(hdr + 4) = sum_inc;
+    if (host_flag) { host_flag[0] = pick; host_flag[1] = seq; }   // pinned host copy: lets the host skip the form that would return at once
+}
+// A note event changes one increment: keep the pick conservative until the next long block recomputes it.
+__device__ __forceinline__ void saw_stats_note(uint32_t *__restrict__ hdr, uint32_t nvoices, uint32_t old_inc, uint32_t new_inc)
+{
+    if (new_inc >= SAW_EVENTS_MAX_INC) hdr[0] = 0u;
+    const unsigned long long d = (unsigned long long)new_inc - (unsigned long long)old_inc;       // mod 2^64
+    const unsigned long long s = atomicAdd(reinterpret_cast<unsigned long long *>(hdr + 4), d) + d;
+    if (s > ((unsigned long long)nvoices << 27)) hdr[0] = 0u;
+}
+
 // Finalize of a TL-frame chunk of the long event form (called from saw_bank_finalize_kernel):
 // thread tid owns the frames FPT*tid .. FPT*tid + FPT-1 of the chunk.
 template <uint32_t TL>
@@ -713,9 +741,8 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ 
         wraps += w[j];
     }
     if (blockIdx.x == 0 && tid == 0 && mode_flag) {
-        const uint32_t f = (MXs < (13u << 25) && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
-        *mode_flag = f;
-        if (host_flag) *host_flag = f;          // pinned host copy: lets the host skip the form that would return at once
+        const uint32_t f = (MXs < SAW_EVENTS_MAX_INC && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
+        saw_stats_publish(mode_flag, host_flag, f, I);
     }
 }
 
@@ -800,9 +827,8 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         // wraps 269 us, 1 % of the voices at 12 wraps 243 us, all at 12 wraps 750 us.
         if (blockIdx.x == 0 && t == 0 && mode_flag) {
             const uint32_t m = max(max(Mx[0], Mx[1]), max(Mx[2], Mx[3]));
-            const uint32_t fl = (m < (13u << 25) && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
-            *mode_flag = fl;
-            if (host_flag) *host_flag = fl;
+            const uint32_t fl = (m < SAW_EVENTS_MAX_INC && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
+            saw_stats_publish(mode_flag, host_flag, fl, I);
         }
     }
 }
@@ -841,12 +867,14 @@ void square_bank_kernel(const uint32_t *__restrict__ inc,
 // Lazy state maintenance (see the header comment).
 // A note event on one voice at elapsed time T: keep state0 + T*inc continuous.
 __global__ void saw_rebase_kernel(uint32_t *__restrict__ inc, uint32_t *__restrict__ state0,
-                                  uint32_t voice, uint32_t new_inc, uint32_t tbase)
+                                  uint32_t voice, uint32_t new_inc, uint32_t tbase,
+                                  uint32_t *__restrict__ hdr, uint32_t nvoices)     // hdr: scratch header or NULL
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const uint32_t old = inc[voice];
         state0[voice] += tbase * (old - new_inc);
         inc[voice] = new_inc;
+        if (hdr) saw_stats_note(hdr, nvoices, old, new_inc);
     }
 }
 // A block's worth of note events at once: pairs[2k] = voice, pairs[2k+1] = its increment after the
@@ -855,7 +883,8 @@ __global__ void saw_rebase_kernel(uint32_t *__restrict__ inc, uint32_t *__restri
 // increment matters).  Voices are distinct, one lane per pair.
 __global__ __launch_bounds__(256)
 void saw_rebase_batch_kernel(uint32_t *__restrict__ inc, uint32_t *__restrict__ state0,
-                             const uint32_t *__restrict__ pairs, uint32_t npairs, uint32_t tbase)
+                             const uint32_t *__restrict__ pairs, uint32_t npairs, uint32_t tbase,
+                             uint32_t *__restrict__ hdr, uint32_t nvoices)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= npairs) return;
@@ -863,6 +892,7 @@ void saw_rebase_batch_kernel(uint32_t *__restrict__ inc, uint32_t *__restrict__ 
     const uint32_t old = inc[voice];
     state0[voice] += tbase * (old - new_inc);
     inc[voice] = new_inc;
+    if (hdr) saw_stats_note(hdr, nvoices, old, new_inc);
 }
 // Materialise every phase: state0 += T*inc (the host then resets T to 0).
 __global__ __launch_bounds__(256)
@@ -1101,19 +1131,20 @@ int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in, uint32
 }
 
 int launch_saw_rebase(uint32_t *d_inc, uint32_t *d_state0, uint32_t voice, uint32_t new_inc,
-                      uint32_t tbase, hipStream_t stream)
+                      uint32_t tbase, void *d_scratch, uint32_t n_pad, hipStream_t stream)
 {
-    hipLaunchKernelGGL(saw_rebase_kernel, dim3(1), dim3(64), 0, stream, d_inc, d_state0, voice, new_inc, tbase);
+    hipLaunchKernelGGL(saw_rebase_kernel, dim3(1), dim3(64), 0, stream, d_inc, d_state0, voice, new_inc, tbase,
+                       static_cast<uint32_t *>(d_scratch), n_pad);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
 
 int launch_saw_rebase_batch(uint32_t *d_inc, uint32_t *d_state0, const uint32_t *d_pairs, uint32_t npairs,
-                            uint32_t tbase, hipStream_t stream)
+                            uint32_t tbase, void *d_scratch, uint32_t n_pad, hipStream_t stream)
 {
     if (npairs == 0) return SMX_OK;
     hipLaunchKernelGGL(saw_rebase_batch_kernel, dim3((npairs + 255) / 256), dim3(256), 0, stream, d_inc,
-                       d_state0, d_pairs, npairs, tbase);
+                       d_state0, d_pairs, npairs, tbase, static_cast<uint32_t *>(d_scratch), n_pad);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

@@ -45,8 +45,8 @@ static inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m
 // to force the direct formulation.
 size_t saw_scratch_bytes(uint32_t max_frames);
 // long_block_form: SMX_FORM_AUTO / SMX_FORM_STEPPING / SMX_FORM_EVENTS (include/synth_mi355x.h)
-// host_flag: pinned (device-visible) word that receives the form the device would pick next
-// (0 stepping, 1 events) after every long block, or NULL.
+// host_flag: two pinned (device-visible) words that receive, after every long block, the form the device
+// would pick next (0 stepping, 1 events) and the number of long blocks finalized so far; or NULL.
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state0, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
                     void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream);
@@ -55,11 +55,12 @@ size_t saw_scratch_header_bytes();
 int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state0, uint32_t *d_or_bus,
                        uint32_t n_pad, uint32_t nframes, uint32_t tbase, hipStream_t stream);
 // one voice's increment changes at elapsed time tbase; state0 += tbase*inc for all voices
+// (d_scratch: the bank's scratch area or NULL -- its header's form pick is kept conservative under note events)
 int launch_saw_rebase(uint32_t *d_inc, uint32_t *d_state0, uint32_t voice, uint32_t new_inc,
-                      uint32_t tbase, hipStream_t stream);
+                      uint32_t tbase, void *d_scratch, uint32_t n_pad, hipStream_t stream);
 // npairs (voice, final increment) pairs with distinct voices, in device memory
 int launch_saw_rebase_batch(uint32_t *d_inc, uint32_t *d_state0, const uint32_t *d_pairs, uint32_t npairs,
-                            uint32_t tbase, hipStream_t stream);
+                            uint32_t tbase, void *d_scratch, uint32_t n_pad, hipStream_t stream);
 int launch_saw_materialize(const uint32_t *d_inc, uint32_t *d_state0, uint32_t n_pad, uint32_t tbase,
                            hipStream_t stream);
 // Carry-out PDM bank (pdm_bank.hip).  n_pad multiple of 1024; d_bits rows are n_pad/8 bytes.

@@ -511,3 +511,57 @@ def test_small_bank_chunk_edges(smx, orc, inc_table, n):
     (tbase != 0) across them."""
     inc, state = synthetic.saw_bank(n, 0x5EED0600 + n, inc_table, active_fraction=0.85)
     _check(smx, orc, inc, state, [15, 16, 17, 1, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 5, 257])
+
+
+def test_auto_form_statistic_is_conservative_under_note_events(smx, orc, inc_table):
+    """AUTO picks the wrap-event form only while the bank's increments are inside the rule (largest below
+    6.5 * 2^26, mean at most 2^27).  The pick is exact as of the last long block and every note event in between
+    keeps it conservative: one voice above the bound, or a running sum above the bound, selects stepping AT ONCE
+    (before any further block), and the next long block recomputes it exactly.  Bits are the same throughout."""
+    FORM_STEPPING, FORM_EVENTS = 1, 2
+    n = 1 << 24
+    inc, state = synthetic.saw_bank(n, 0x5EED0700, inc_table)          # piano range: inside the rule
+    inc[:4096] = 0                                                      # free voices for the note-ons below
+    bank = smx.SawBank(n)
+    bank.load(inc, state)
+    st = state.copy()
+
+    def block():
+        bus, _ = bank.run(64)
+        obus, _ = oracle.synth_run(orc, inc, st, 64, want_vec=False)
+        assert np.array_equal(bus, obus)
+
+    assert bank.next_block_form() == FORM_STEPPING                      # after a load: unknown -> stepping
+    block()
+    assert bank.next_block_form() == FORM_EVENTS                        # measured by that block: inside the rule
+    block()
+    # one very high voice (MIDI 127: 16.7 wraps per 64 frames): stepping at once
+    n2v = np.zeros(128, np.int32)
+    bank.note_on(127)
+    orc.orc_note_on(n2v, inc, n, 127)
+    assert bank.next_block_form() == FORM_STEPPING
+    block()
+    assert bank.next_block_form() == FORM_STEPPING                      # exact statistic: the voice is still there
+    bank.note_off(127)
+    orc.orc_note_off(n2v, inc, n, 127)
+    assert bank.next_block_form() == FORM_STEPPING                      # conservative until the next long block
+    block()
+    assert bank.next_block_form() == FORM_EVENTS
+    # a burst of note-ons below the per-voice bound that lifts the MEAN above 2 wraps: the running sum trips it
+    # (the bank's mean is ~1.1 wraps; 4096 voices cannot do it, so load a bank close to the bound first)
+    inc2 = np.full(n, (1 << 27) - 3000, np.uint32)
+    inc2[:4096] = 0
+    inc[:] = inc2
+    bank.load(inc=inc2)
+    block()
+    assert bank.next_block_form() == FORM_EVENTS                        # mean just below 2 wraps
+    ev = np.array([[0x90, 100 + (k % 8), 100] for k in range(3000)], np.uint8)   # notes 100..107: 3.6 .. 5.3 wraps each
+    bank.midi_events(ev)
+    for m in ev:
+        orc.orc_midi_event(n2v, inc, n, np.ascontiguousarray(m), 3)
+    assert bank.next_block_form() == FORM_STEPPING
+    block()
+    block()
+    _, gst = bank.read()
+    assert np.array_equal(gst, st)
+    bank.close()

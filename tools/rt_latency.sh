@@ -7,10 +7,10 @@ for v in 64 65536 1048576 16777216 67108864 268435456; do
   SYNTH_FILL=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync      /"
   SYNTH_FILL=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v SYNTH_PIPELINE=1 ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/pipelined /"
 done
-# worst case for the wrap-event form: every voice at 12 wraps per block.  Default form (stepping): the callback's
-# time does not depend on what is played; SYNTH_FORM_AUTO=1 lets the device pick (it keeps stepping on this bank)
+# worst case for the wrap-event form: every voice at 12 wraps per block.  Default (AUTO): the device's statistic keeps
+# the stepping form on this bank, so the callback takes the stepping form's time; SYNTH_FORM_STEPPING=1 pins that form.
 for v in 16777216 67108864 268435456; do
-  SYNTH_FILL=worst SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync worst-case bank, default form      /"
-  SYNTH_FILL=worst SYNTH_FORM_AUTO=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync worst-case bank, SYNTH_FORM_AUTO=1 /"
-  SYNTH_FILL=1 SYNTH_FORM_AUTO=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync piano-range bank, SYNTH_FORM_AUTO=1 /"
+  SYNTH_FILL=worst SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync worst-case bank, default (AUTO)        /"
+  SYNTH_FILL=worst SYNTH_FORM_STEPPING=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync worst-case bank, SYNTH_FORM_STEPPING=1  /"
+  SYNTH_FILL=1 SYNTH_FORM_STEPPING=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync piano-range bank, SYNTH_FORM_STEPPING=1 /"
 done
