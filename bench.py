@@ -652,7 +652,9 @@ def run_rank(a):
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "recorded: profiles/traffic.json (rocprofv3 --pmc passes of this command), "
                                            "not measured in this run" if traffic else None,
-                         "kernel": "saw_bank_kernel", "kernel_ms": round(kernel_ms, 5),
+                         "kernel": "saw_tick_kernel" if (a.frames <= 4 and a.voices >= 1 << 20 and a.voices % 4096 == 0)
+                                   else "saw_bank_kernel",
+                         "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_voice": 8,
                          "note": "8 B read per voice per launch (inc + phase base); the advanced phase is kept as "

@@ -1069,10 +1069,14 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             return SMX_OK;
         }
     }
-    if (nframes <= 4 && n_pad >= (1u << 20) && n_pad < (1u << 26) && (n_pad & 4095) == 0) {
-        // tick ABI on a 2^20..2^26-voice bank: 1024-thread streaming workgroups, >= 4 rows each
-        // (measured: 16 Mi voices 19.6 us vs 27.4 us with 256-thread workgroups; from 64 Mi voices
-        // up the 1024 x 256-thread grid of saw_bank_kernel is 3 % faster)
+    static const char *tm = getenv("SMX_SAW_TICK_MAX_LOG2");           // tuning override
+    static const unsigned tick_max_log2 = tm ? (unsigned)atoi(tm) : 33u;     // no upper bound (round 2: see below)
+    if (nframes <= 4 && n_pad >= (1u << 20) && (unsigned long long)n_pad < (1ull << tick_max_log2) && (n_pad & 4095) == 0) {
+        // tick ABI on a bank of 2^20 voices or more: 1024-thread streaming workgroups, >= 4 rows each, 256
+        // of them = one per CU (measured: 16 Mi voices 19.6 us vs 27.4 us with 256-thread workgroups; 64 Mi
+        // voices 74.7 us = 7.18 TB/s vs 78.3 us for the 1024 x 256-thread grid of saw_bank_kernel, 256 Mi
+        // voices 302 vs 317 us, 32 and 128 Mi voices equal; a grid that is not a multiple of the 256 CUs,
+        // e.g. 320, loses 35 %)
         const uint32_t ngroups = n_pad / 4, nrows = ngroups >> 10;
         static const char *tg = getenv("SMX_SAW_TICK_GRID");           // tuning override
         uint32_t gx = nrows / 4;

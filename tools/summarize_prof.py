@@ -21,7 +21,7 @@ os.makedirs(dst, exist_ok=True)
 
 stats = max(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
-for leg in ("trace", "fetch", "write"):
+for leg in ("unprofiled", "trace", "fetch", "write"):
     p = os.path.join(src, "bench_%s.json" % leg)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, "%s_bench_%s.json" % (tag, leg)))
