@@ -87,6 +87,7 @@ def launch_ranks(n):
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
     live = set(range(n))
+    failed_at = None
     while live:
         for r in sorted(live):
             code = procs[r].poll()
@@ -95,9 +96,15 @@ def launch_ranks(n):
             live.discard(r)
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
-                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
-                for o in sorted(live):
-                    procs[o].terminate()             # exactly the children we started
+                failed_at = time.monotonic()
+                sys.stderr.write("bench.py: rank %d exited with %d\n" % (r, code))
+        # a failed rank leaves the others waiting at the rendezvous or in a collective: give them a moment to
+        # fail by themselves (and say why), then stop exactly the children we started
+        if failed_at is not None and live and time.monotonic() - failed_at > 3.0:
+            sys.stderr.write("bench.py: stopping the other ranks\n")
+            for o in sorted(live):
+                procs[o].terminate()
+            failed_at = float("inf")
         time.sleep(0.05)
     try:
         for f in os.listdir(rdzv):
