@@ -209,7 +209,9 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     if (device < 0 || device >= ndev) { set_error("smx_bank_create: device %d of %d", device, ndev); return nullptr; }
     smx_bank *b = new smx_bank();
     b->n = n_voices;
-    b->n_pad = smx::round_up(n_voices, 1024);
+    // padding voices are off forever; big banks are padded to whole 4096-voice rows so that ragged sizes take
+    // the 1024-thread tick kernel too (saw_bank.hip)
+    b->n_pad = smx::round_up(n_voices, n_voices >= (1u << 20) ? 4096u : 1024u);
     b->device = device;
     auto fail = [&](const char *what, hipError_t e) -> smx_bank * {
         set_error("smx_bank_create: %s: %s", what, hipGetErrorString(e));
