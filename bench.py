@@ -574,6 +574,10 @@ def run_rank(a):
 
     L = sta.lib()
     ndev = L.smx_device_count()
+    if os.environ.get("SMX_BENCH_DEVICES"):
+        # rehearsal on fewer GPUs than ranks (tests/test_multi_rank_gpu.py with its RCCL test double): "0,0" = both
+        # ranks on device 0.  Real RCCL refuses two ranks on one device.
+        local = int(os.environ["SMX_BENCH_DEVICES"].split(",")[local])
     if ndev <= local:
         sys.exit("bench.py: rank %d: no GPU visible for local rank %d (%d device(s); there is no CPU fallback)"
                  % (rank, local, ndev))

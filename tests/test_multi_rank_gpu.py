@@ -15,12 +15,29 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(world, devices, voices=5000, timeout=240):
+def _fake_rccl():
+    """tests/c/fake_rccl.cpp (a shared-memory test double of the seven RCCL entry points the product calls),
+    built on the box with hipcc.  None if it cannot be built."""
+    src = os.path.join(HERE, "c", "fake_rccl.cpp")
+    out = os.path.join(tempfile.gettempdir(), "smx_fake_rccl_%d.so" % os.getuid())
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if not os.path.exists(hipcc):
+            return None
+        p = subprocess.run([hipcc, "-O2", "-shared", "-fPIC", "-o", out, src, "-lrt"], capture_output=True, text=True)
+        if p.returncode != 0:
+            return None
+    return out
+
+
+def _run(world, devices, voices=5000, timeout=240, preload=None):
     rdzv = tempfile.mkdtemp(prefix="smx_rdzv_test_")
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), SMX_RDZV_DIR=rdzv,
                    SMX_TEST_DEVICE=str(devices[r]), SMX_TEST_VOICES=str(voices), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if preload:
+            env["LD_PRELOAD"] = preload
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mgpu_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     out = []
@@ -55,3 +72,43 @@ def test_two_ranks_sum_their_shards(smx, voices):
         assert rc == 0, e[-2000:]
         r = json.loads(o.strip().splitlines()[-1])
         assert r["ranks_seen"] == 2 and r["checks"] >= 20
+
+
+@pytest.mark.parametrize("world,voices", [(2, 5000), (4, 70000), (2, 1 << 20)])
+def test_ranks_sharing_the_gpu_through_the_rccl_test_double(smx, world, voices):
+    """2 and 4 PROCESSES, each with its shard of the bank on the one GPU, the library's communicator path end to
+    end, with tests/c/fake_rccl.cpp standing in for librccl (RCCL itself refuses two ranks on one device).  The
+    double sums through shared memory AND checks that every rank issues the same collectives with the same counts.
+    Every mode that hands out a reduced bus must equal the oracle run over ALL shards."""
+    fake = _fake_rccl()
+    if fake is None:
+        pytest.skip("hipcc not available to build the RCCL test double")
+    res = _run(world, [0] * world, voices=voices, preload=fake)
+    for rc, o, e in res:
+        assert rc == 0, e[-3000:]
+        r = json.loads(o.strip().splitlines()[-1])
+        assert r["ranks_seen"] == world and r["checks"] >= 20
+        assert r["grouped_block_sums"] == 20 and r["grouped_collectives"] <= 5
+
+
+def test_bench_with_two_ranks_on_the_one_gpu(smx):
+    """`python bench.py --gpus 2` end to end on the one-GPU box: its own launcher, the socket rendezvous, the
+    library's communicator (the RCCL test double underneath), the timed loop with one collective per 8 steps, and
+    the bus check SUMMED OVER BOTH RANKS against the closed form.  The rate it prints means nothing here (the double
+    blocks); that the line appears with ranks_seen = 2 and the check passed is the point."""
+    fake = _fake_rccl()
+    if fake is None:
+        pytest.skip("hipcc not available to build the RCCL test double")
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(LD_PRELOAD=fake, SMX_BENCH_DEVICES="0,0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--voices", str(1 << 20),
+                        "--frames", "64", "--steps", "40", "--warmup", "5"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert "summed over 2 ranks" in line["verified"]
+    assert line["config"]["voices_total"] == 2 << 20
+    # 45 blocks + the checked one; one collective per 8 blocks (+ the ring's wrap and the final flushes)
+    assert line["collectives"]["block_sums_carried"] == 46 and line["collectives"]["issued"] <= 10
