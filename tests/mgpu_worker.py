@@ -34,6 +34,17 @@ def main():
     def expect(nf):
         return oracle.synth_run(orc, all_inc, all_st, nf)
 
+    if os.environ.get("SMX_TEST_VIOLATE"):
+        # the SPMD contract broken on purpose: only rank 0 fetches in the middle of a group, so the ranks would
+        # issue different collectives (3 blocks + 5 blocks vs 8 blocks).  With the test double this aborts.
+        for k in range(8):
+            bank.run_async(64)
+            bank.allreduce_async(64)
+            if k == 2 and rank == 0:
+                bank.fetch(64)
+        bank.sync()
+        print(json.dumps({"rank": rank, "violation_went_unnoticed": True}))
+        return
     # (1) sync mode: smx_bank_run returns the sum over all ranks
     for nf in (64, 1, 7, 64, 300):
         bus, vec = bank.run(nf)

@@ -30,7 +30,7 @@ def _fake_rccl():
     return out
 
 
-def _run(world, devices, voices=5000, timeout=240, preload=None):
+def _run(world, devices, voices=5000, timeout=240, preload=None, extra_env=None):
     rdzv = tempfile.mkdtemp(prefix="smx_rdzv_test_")
     procs = []
     for r in range(world):
@@ -38,6 +38,7 @@ def _run(world, devices, voices=5000, timeout=240, preload=None):
                    SMX_TEST_DEVICE=str(devices[r]), SMX_TEST_VOICES=str(voices), HSA_ENABLE_IPC_MODE_LEGACY="0")
         if preload:
             env["LD_PRELOAD"] = preload
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mgpu_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     out = []
@@ -112,3 +113,16 @@ def test_bench_with_two_ranks_on_the_one_gpu(smx):
     assert line["config"]["voices_total"] == 2 << 20
     # 45 blocks + the checked one; one collective per 8 blocks (+ the ring's wrap and the final flushes)
     assert line["collectives"]["block_sums_carried"] == 46 and line["collectives"]["issued"] <= 10
+
+
+def test_the_test_double_catches_a_broken_spmd_contract(smx):
+    """include/synth_mi355x.h: with a communicator every rank makes the same sequence of calls.  A rank that
+    fetches in the middle of a group on its own would issue other collectives than its peers -- real RCCL would
+    hang or mis-sum; the test double names it."""
+    fake = _fake_rccl()
+    if fake is None:
+        pytest.skip("hipcc not available to build the RCCL test double")
+    res = _run(2, [0, 0], preload=fake, extra_env={"SMX_TEST_VIOLATE": "1"}, timeout=200)
+    assert any(rc != 0 for rc, _, _ in res)
+    assert any("SPMD contract" in e or "different collectives" in e for _, _, e in res)
+    assert not any("violation_went_unnoticed" in o for _, o, _ in res if o)
