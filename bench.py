@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # everything VOP3-only or carry-writing (v_add3, v_add_co, v_addc_co, v_mul_lo, v_perm, v_cndmask ...) ~4.5.
 # The kernels' inner loops in those units, per 64 units of work (one wave instruction each lane-op):
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
-ISSUE = {"saw_direct": 2.66 + 2.85 + 0.5 * 4.72,      # v_ashrrev + v_add (phase) + half a v_add3 per voice-sample
+ISSUE = {"saw_direct": 2.66 + 2.85 + 2.85,            # v_ashrrev + v_add (phase) + v_add (accumulate) per voice-sample
          "saw_carry": (4 * 4.46 + 2 * 4.41) / 4,      # 4 v_add_co + 2 v_addc_co per 4 voice-samples (+ scalar popcounts)
          "pdm_tick_major": 10.0,                      # v_add_co + s_nop 1 + 2 v_writelane, measured as a sequence
          "pdm_stream": 4.46 + 4.41,                   # v_add_co + v_addc_co
@@ -404,7 +404,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
     if "saw_frames" in legs:
         # longer blocks of the same bank; 64 frames = the JACK operating point (linux/jack_midi.c:19-20)
         for frames in (8, 16, 32, 64, 1024):
-            carry = frames > 16 and voices * frames >= 1 << 30
+            carry = frames > 32 and voices * frames >= 1 << 30
             # blocks of more than 32 frames have two exact forms: AUTO (default) lets the device pick from the bank's
             # increments, STEPPING is the data-independent one (also what AUTO falls back to: DESIGN 3.2b)
             for form in ((SMX_FORM_AUTO, SMX_FORM_STEPPING) if (carry and frames > 32) else (SMX_FORM_AUTO,)):

@@ -26,7 +26,7 @@
 //    event rebases one voice: state0 += T*(inc_old - inc_new) (saw_rebase_kernel), which
 //    keeps state0 + T*inc continuous -- the reference's "note_on does not reset the phase".
 //
-// Long blocks of big banks (> 16 frames, >= 2^30 voice-samples) take a second formulation
+// Long blocks of big banks (> 32 frames, >= 2^30 voice-samples) take a second formulation
 // (saw_bank_carry_kernel) that needs 2 instead of 2.5 vector ops per voice-sample:
 // with u = state ^ 0x80000000 (offset binary) the arithmetic shift becomes a logical
 // one, (int)state >> 4 == (u >> 4) - 2^27, and because every term is a floor,
@@ -61,6 +61,30 @@ __device__ __forceinline__ T stream_load(const T *p)
 {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
+}
+// acc += p0 + p1 + p2 + p3.  Left to itself the compiler writes two v_add3_u32; PLAIN spells it as four
+// two-operand v_add_u32 (pair sums first, so the chain on the accumulator stays two adds long).  Which one is faster
+// depends on how many waves a SIMD holds (same-box A/B of the whole kernel, tools/ab_add3.sh): with 8 waves per SIMD
+// -- banks of 2^24 voices and more -- the launch is bound by issue THROUGHPUT and the plain adds win, because
+// v_add_u32 issues in 2.9 cycles and v_add3_u32 in 4.7 (64 Mi voices: 16 frames 97.2 -> 94.5 us, 32 frames 156 ->
+// 140, 64 frames 289 -> 241); with the 4 waves per SIMD that a 2^20..2^22-voice bank leaves, a wave's own issue rate
+// bounds the launch and the shorter instruction stream wins (1 Mi voices x 64 frames: 9.5 us with v_add3, 10.3 with
+// plain adds).  The kernels pass their NT flag (set from 2^24 voices up) as PLAIN.
+template <bool PLAIN>
+__device__ __forceinline__ void acc_add4(int32_t &acc, int32_t p0, int32_t p1, int32_t p2, int32_t p3)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (PLAIN) {
+        int32_t t0, t1;
+        asm("v_add_u32 %0, %1, %2" : "=v"(t0) : "v"(p0), "v"(p1));
+        asm("v_add_u32 %0, %1, %2" : "=v"(t1) : "v"(p2), "v"(p3));
+        asm("v_add_u32 %0, %0, %1" : "+v"(acc) : "v"(t0));
+        asm("v_add_u32 %0, %0, %1" : "+v"(acc) : "v"(t1));
+        return;
+    }
+#endif
+    acc += p0 + p1;
+    acc += p2 + p3;
 }
 // Partial sums of one 64-frame chunk.  Workgroups add into one of a few slots per chunk
 // (few adders per address); saw_bank_finalize_kernel sums the slots and clears them.
@@ -171,8 +195,7 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
 #pragma unroll
         for (int t = 0; t < TC; t++) {
             if constexpr (VW == 4) {
-                acc[t] += ((int32_t)vs[0] >> 4) + ((int32_t)vs[1] >> 4);
-                acc[t] += ((int32_t)vs[2] >> 4) + ((int32_t)vs[3] >> 4);
+                acc_add4<NT>(acc[t], (int32_t)vs[0] >> 4, (int32_t)vs[1] >> 4, (int32_t)vs[2] >> 4, (int32_t)vs[3] >> 4);
             } else {
                 acc[t] += ((int32_t)vs[0] >> 4);
             }
@@ -263,8 +286,7 @@ void saw_tick_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restric
         s.x = a.x ? s.x : 0u; s.y = a.y ? s.y : 0u; s.z = a.z ? s.z : 0u; s.w = a.w ? s.w : 0u;
 #pragma unroll
         for (int t = 0; t < TC; t++) {
-            acc[t] += ((int32_t)s.x >> 4) + ((int32_t)s.y >> 4);
-            acc[t] += ((int32_t)s.z >> 4) + ((int32_t)s.w >> 4);
+            acc_add4<false>(acc[t], (int32_t)s.x >> 4, (int32_t)s.y >> 4, (int32_t)s.z >> 4, (int32_t)s.w >> 4);
             s += a;
         }
     }
@@ -314,7 +336,8 @@ __device__ __forceinline__ uint32_t carry_step4(uint32_t &u0, uint32_t &u1, uint
 }
 
 // MULTI: more than one 64-frame chunk per launch (blockIdx.y).
-// TC: frames computed per chunk (64, or 32 for single-chunk blocks of 17..32 frames).
+// TC: frames computed per chunk (64; blocks of up to 32 frames run the direct form, which is faster there since
+//   its accumulate became plain adds: 64 Mi voices x 32 frames 135 us against 138 us for a 32-frame stepping chunk).
 // EVENTS: the wraps are not found by stepping the phases but located directly (TC == 64 only):
 //   first wrap of a voice at frame  n1 = floor(~u / inc)            (u: offset-binary phase at chunk start)
 //   then gaps of                    Q + (r <= R),  Q = floor((2^32-1)/inc),  R = 2^32-1 - Q*inc
@@ -331,7 +354,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
                            const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
 {
     static_assert(!EVENTS || TC == 64, "the event form is built for 64-frame chunks");
-    static_assert(TC == 32 || TC == 64, "frames per chunk");
+    static_assert(TC == 64, "frames per chunk");
     __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
     __shared__ unsigned long long S[2];            // U0, I
@@ -998,7 +1021,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     static const unsigned carry_min_log2 = cm ? (unsigned)atoi(cm) : 30u;
     const bool big = (unsigned long long)n_pad * nframes >= (1ull << carry_min_log2);
     // (banks from 2^16 voices: 256 Ki voices x 4096 frames 70 -> 44 us, x 16384 frames 260 -> 120 us)
-    if (nframes > 16 && n_pad >= (1u << 16) && big && d_scratch && !no_carry) {
+    if (nframes > 32 && n_pad >= (1u << 16) && big && d_scratch && !no_carry) {
         // carry-count formulation: 2 vector ops per voice-sample
         const uint32_t ngroups = n_pad / 4;
         const uint32_t gy = (nframes + 63) / 64;
@@ -1047,7 +1070,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                     else            { if (nt) SMX_LONG_LAUNCH(true, 256);  else SMX_LONG_LAUNCH(false, 256); }
 #undef SMX_LONG_LAUNCH
                 }
-            } else if (nframes > 32) {
+            } else {
                 // 64-frame chunks: both forms are queued, the device-side flag picks one (the other
                 // returns at once); the finalize kernel refreshes the flag from this launch's statistics
                 const uint32_t *f = (no_events || force_events) ? nullptr : flag;
@@ -1059,8 +1082,6 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                     if (gy > 1) { if (nt) SMX_CARRY_LAUNCH(true, true, 64, true, f);  else SMX_CARRY_LAUNCH(false, true, 64, true, f); }
                     else        { if (nt) SMX_CARRY_LAUNCH(true, false, 64, true, f); else SMX_CARRY_LAUNCH(false, false, 64, true, f); }
                 }
-            } else {
-                if (nt) SMX_CARRY_LAUNCH(true, false, 32, false, nullptr); else SMX_CARRY_LAUNCH(false, false, 32, false, nullptr);
             }
 #undef SMX_CARRY_LAUNCH
             hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
