@@ -335,6 +335,23 @@ __device__ __forceinline__ uint32_t carry_step4(uint32_t &u0, uint32_t &u1, uint
 #endif
 }
 
+// floor(a / d) for a quotient known to be below 2^11, with ONE reciprocal per divisor shared by all quotients of a
+// voice: the estimate (float)a * rd, rd = rcp((float)d) * (1 - 2^-18), lies below the true ratio by less than
+// 2^-17.5 of it (three roundings of 2^-24 .. 2^-23 each against a bias of 2^-18), i.e. by less than 0.006 for ratios
+// below 2^11 -- so its floor is the quotient or one less, and one compare settles it.  The generic 32-bit division
+// the compiler emits is ~25 instructions; this is 6.  (Only voices that wrap within the chunk are divided, and for
+// those both quotients are below the chunk length or irrelevant: see the callers.)
+__device__ __forceinline__ float rcp_biased(uint32_t d)
+{
+    return __builtin_amdgcn_rcpf((float)d) * 0.99999618530273437500f;      // 1 - 2^-18
+}
+__device__ __forceinline__ uint32_t div_small(uint32_t a, uint32_t d, float rd)
+{
+    uint32_t q = (uint32_t)((float)a * rd);
+    const uint32_t r = a - q * d;                 // q <= the true quotient: no wrap
+    return r >= d ? q + 1u : q;
+}
+
 // MULTI: more than one 64-frame chunk per launch (blockIdx.y).
 // TC: frames computed per chunk (64; blocks of up to 32 frames run the direct form, which is faster there since
 //   its accumulate became plain adds: 64 Mi voices x 32 frames 135 us against 138 us for a 32-frame stepping chunk).
@@ -441,12 +458,14 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
                     const uint32_t e = lane + 64u * k;
                     const uint2 en = list[e < nw ? e : 0u];
                     const uint32_t d = en.y;                  // > 0: an off voice never wraps
-                    const uint32_t n1 = ~en.x / d;
-                    eq[k] = 0xFFFFFFFFu / d;
-                    erm[k] = 0xFFFFFFFFu - eq[k] * d;
+                    const float rd = rcp_biased(d);
+                    // the voice wraps within the chunk, so ~u < 64 d: the first quotient is below 64
+                    const uint32_t n1 = div_small(~en.x, d, rd);
+                    // Q < 64 exactly when d >= 2^26; a smaller increment wraps at most once per chunk and any
+                    // gap beyond the chunk is as good as any other (2^30 keeps et + gap from wrapping)
+                    eq[k] = (d >> 26) ? div_small(0xFFFFFFFFu, d, rd) : (1u << 30);
+                    erm[k] = 0xFFFFFFFFu - eq[k] * d;         // (meaningless, and unused, in the second case)
                     ee[k] = d - 1u - erm[k];
-                    eq[k] = min(eq[k], 1u << 30);             // a gap beyond the chunk is as good as any other:
-                                                              // keeps et + gap from wrapping (inc == 1: Q = 2^32-1)
                     er[k] = en.x + (n1 + 1u) * d;             // mod 2^32: the phase right after the first wrap
                     ei[k] = d;
                     if (e < nw) et[k] = n1;
@@ -632,11 +651,12 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
             const uint32_t e = lane + 64u * k;
             const uint2 en = list[e < nw ? e : 0u];
             const uint32_t d = en.y;
-            const uint32_t n1 = ~en.x / d;
-            uint32_t eq = 0xFFFFFFFFu / d;
+            const float rd = rcp_biased(d);
+            const uint32_t n1 = div_small(~en.x, d, rd);      // < TL: the voice wraps within the chunk
+            // Q < TL exactly when d >= 2^(32-LG); below that the next wrap lies beyond the chunk anyway
+            const uint32_t eq = (d >> (32 - LG)) ? div_small(0xFFFFFFFFu, d, rd) : (1u << 30);
             const uint32_t erm = 0xFFFFFFFFu - eq * d;
             const uint32_t ee = d - 1u - erm;
-            eq = min(eq, 1u << 30);                           // keeps et + gap from wrapping (inc == 1)
             uint32_t er = en.x + (n1 + 1u) * d;               // the phase right after the first wrap
             uint32_t et = e < nw ? n1 : 0xFFFFFFFFu;
             // every gap is at least one frame: TL rounds always suffice
