@@ -193,6 +193,10 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
         SMX_HIP(hipMalloc(&b->d_scratch, smx::saw_scratch_bytes(scap)));
         SMX_HIP(hipMemset(b->d_scratch, 0, smx::saw_scratch_bytes(scap)));   // slots are kept zero between launches
         b->scratch_cap = scap;
+        // a new header: the form pick starts at "stepping", the sum of the increments is computed again
+        int rv = smx::launch_saw_sum_inc(b->d_inc, b->n_pad, b->d_scratch, b->stream);
+        if (rv) return rv;
+        bank_form_unpin(b);
     }
     b->bus_cap = cap;
     return SMX_OK;
@@ -301,7 +305,11 @@ extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *s
         b->free_map.load(inc, b->n);
         // new increments: the statistic that picks the long-block form is void (stepping until the
         // next long block has measured the new bank)
-        if (b->d_scratch) SMX_HIP(hipMemsetAsync(b->d_scratch, 0, smx::saw_scratch_header_bytes(), b->stream));
+        if (b->d_scratch) {
+            SMX_HIP(hipMemsetAsync(b->d_scratch, 0, smx::saw_scratch_header_bytes(), b->stream));
+            rv = smx::launch_saw_sum_inc(b->d_inc, b->n_pad, b->d_scratch, b->stream);    // the header's sum of increments
+            if (rv) return rv;
+        }
         bank_form_unpin(b);
     }
     if (state)

@@ -94,7 +94,7 @@ __device__ __forceinline__ void acc_add4(int32_t &acc, int32_t p0, int32_t p1, i
 constexpr int SAW_SLOTS = 64;       // slots per chunk (unused ones stay zero)
 struct SawPartial {
     unsigned long long L[64];     // sum over voices of (u_v(t) & 15)
-    unsigned long long U0, I;     // sum u_v(t0), sum inc_v
+    unsigned long long U0;        // sum u_v(t0)
     uint32_t W[64];               // carries out of the phase add at frame t (t -> t+1)
     uint32_t maxinc, pad_;        // largest increment seen (statistic for the next launch's formulation)
 };
@@ -103,8 +103,10 @@ struct SawPartial {
 //       their start -- the one that is not selected returns at once;
 //   [1] which slot layout the launch filled (for the finalize kernel);
 //   [2] number of long blocks finalized so far (copied to the host's mirror: tells a fresh pick from an old one);
-//   [4..5] exact sum of all increments as of the last long block, kept current by the note-event kernels.
-// The finalize kernel writes [0] from the launch's own statistics (largest increment, sum of increments).
+//   [4..5] exact sum of all increments: computed when the increments are loaded (saw_sum_inc_kernel), kept
+//          current by the note-event kernels; the finalize kernels take the bank's I from here (the main kernels
+//          do not add the increments up again at every launch).
+// The finalize kernel writes [0] from the launch's own largest increment and the sum of increments.
 // Note events keep it CONSERVATIVE in between: a new increment above the bound, or a running sum above the
 // bound, clears [0] at once (saw_stats_note), so that the event form never runs on a bank the rule would not
 // admit -- that is what bounds AUTO's run time.  Both forms are exact for any bank; the flag
@@ -374,7 +376,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     static_assert(TC == 64, "frames per chunk");
     __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
-    __shared__ unsigned long long S[2];            // U0, I
+    __shared__ unsigned long long S[1];            // U0
     __shared__ uint32_t MX;                        // largest increment
     __shared__ uint2 EL[EVENTS ? 4 * 256 : 1];     // EVENTS: per wave, the (phase, inc) of the voices that wrap
     if (mode_flag && (*mode_flag != 0u) != EVENTS) return;     // the other form runs this launch
@@ -395,7 +397,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
 #pragma unroll
         for (int t = 0; t < 32; t++) W[t] = 0;
     }
-    unsigned long long sumU = 0, sumI = 0;
+    unsigned long long sumU = 0;
     uint32_t mx = 0;
 
     // ngroups is a multiple of 256 (n_pad of 1024): whole workgroup rows, so the trip count is
@@ -423,7 +425,6 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         uint32_t u2 = (a.z ? b.z + t0 * a.z : 0u) ^ 0x80000000u;
         uint32_t u3 = (a.w ? b.w + t0 * a.w : 0u) ^ 0x80000000u;
         sumU += (unsigned long long)u0 + u1 + u2 + u3;
-        sumI += (unsigned long long)a.x + a.y + a.z + a.w;
         atomicAdd(&H[((u0 & 15) << 4) | (a.x & 15)], 1u);
         atomicAdd(&H[((u1 & 15) << 4) | (a.y & 15)], 1u);
         atomicAdd(&H[((u2 & 15) << 4) | (a.z & 15)], 1u);
@@ -512,8 +513,8 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     }
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
     if (lane == 0) atomicMax(&MX, mx);
-    for (int o = 32; o > 0; o >>= 1) { sumU += __shfl_xor(sumU, o); sumI += __shfl_xor(sumI, o); }
-    if (lane == 0) { atomicAdd(&S[0], sumU); atomicAdd(&S[1], sumI); }
+    for (int o = 32; o > 0; o >>= 1) sumU += __shfl_xor(sumU, o);
+    if (lane == 0) atomicAdd(&S[0], sumU);
     __syncthreads();
 
     SawPartial *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
@@ -541,7 +542,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         l += __shfl_xor(l, 2);
         if (q == 0) atomicAdd(&out->L[t], l);
     }
-    if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicAdd(&out->I, S[1]); atomicMax(&out->maxinc, MX); }
+    if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicMax(&out->maxinc, MX); }
 }
 
 // The event form for launches of 256 frames and more: 256-frame chunks, so that the divisions are
@@ -551,7 +552,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
 // (TL = 256; launches of 1024 frames and more use 1024-frame chunks, TL = 1024.)
 template <uint32_t TL>
 struct SawPartialL {
-    unsigned long long U0, I;     // sum u_v(t0), sum inc_v
+    unsigned long long U0;        // sum u_v(t0)
     uint32_t maxinc, pad_;
     uint32_t H[256];              // voices per (phase & 15, inc & 15) class
     uint32_t W[TL];               // wraps at frame t (t -> t+1)
@@ -582,7 +583,7 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
     if (tid == 0) MX = 0;
     __syncthreads();
 
-    unsigned long long sumU = 0, sumI = 0;
+    unsigned long long sumU = 0;
     uint32_t mx = 0;
     const uint32_t nrows = ngroups >> 8;
     const u32x4 *inc4 = reinterpret_cast<const u32x4 *>(inc);
@@ -605,7 +606,6 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
         vu[2] = (a.z ? b.z + t0 * a.z : 0u) ^ 0x80000000u;
         vu[3] = (a.w ? b.w + t0 * a.w : 0u) ^ 0x80000000u;
         sumU += (unsigned long long)vu[0] + vu[1] + vu[2] + vu[3];
-        sumI += (unsigned long long)a.x + a.y + a.z + a.w;
         mx = max(max(mx, a.x), max(max(a.y, a.z), a.w));
         // (1) The wave sorts its wrapping voices by the binary order of their wrap count K (a counting
         //     sort over 9 classes in LDS): dealt out lane by lane afterwards, slot k of every lane then
@@ -674,28 +674,31 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
     }
     for (int o = 32; o > 0; o >>= 1) {
         sumU += __shfl_xor(sumU, o);
-        sumI += __shfl_xor(sumI, o);
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
     }
-    if (lane == 0) { atomicAdd(&S[0], sumU); atomicAdd(&S[1], sumI); atomicMax(&MX, mx); }
+    if (lane == 0) { atomicAdd(&S[0], sumU); atomicMax(&MX, mx); }
     __syncthreads();
     SawPartialL<TL> *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
     for (uint32_t i = tid; i < TL; i += 256)
         if (hist[i]) atomicAdd(&out->W[i], hist[i]);
     if (H[tid]) atomicAdd(&out->H[tid], H[tid]);
-    if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicAdd(&out->I, S[1]); atomicMax(&out->maxinc, MX); }
+    if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicMax(&out->maxinc, MX); }
 }
 
 // End of a long block: the exact statistics of this launch (header words above) and the host's mirror
 // {pick, number of long blocks finalized}.
 __device__ __forceinline__ void saw_stats_publish(uint32_t *__restrict__ hdr, uint32_t *__restrict__ host_flag,
-                                                  uint32_t pick, unsigned long long sum_inc)
+                                                  uint32_t pick)
 {
     hdr[0] = pick;
     const uint32_t seq = hdr[2] + 1u;
     hdr[2] = seq;
-    *reinterpret_cast<unsigned long long *>(hdr + 4) = sum_inc;
     if (host_flag) { host_flag[0] = pick; host_flag[1] = seq; }   // pinned host copy: lets the host skip the form that would return at once
+}
+// I = the sum of all increments of the bank (header words [4..5], exact: see SAW_SCRATCH_HEADER)
+__device__ __forceinline__ unsigned long long saw_stats_sum_inc(const uint32_t *__restrict__ hdr)
+{
+    return *reinterpret_cast<const unsigned long long *>(hdr + 4);
 }
 // A note event changes one increment: keep the pick conservative until the next long block recomputes it.
 __device__ __forceinline__ void saw_stats_note(uint32_t *__restrict__ hdr, uint32_t nvoices, uint32_t old_inc, uint32_t new_inc)
@@ -716,7 +719,7 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ 
 {
     constexpr uint32_t FPT = TL / 256;
     __shared__ uint32_t Hs[256], Wsum[4];
-    __shared__ unsigned long long US[2];
+    __shared__ unsigned long long US[1];
     __shared__ uint32_t MXs;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SawPartialL<TL> *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
@@ -741,15 +744,14 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ 
     }
     Hs[tid] = h;
     if (wave == 0) {                                          // lane s folds slot s's scalars
-        unsigned long long u0 = p[lane].U0, ii = p[lane].I;
+        unsigned long long u0 = p[lane].U0;
         uint32_t m = p[lane].maxinc;
-        p[lane].U0 = 0; p[lane].I = 0; p[lane].maxinc = 0;
+        p[lane].U0 = 0; p[lane].maxinc = 0;
         for (int o = 32; o > 0; o >>= 1) {
             u0 += __shfl_xor(u0, o);
-            ii += __shfl_xor(ii, o);
             m = max(m, (uint32_t)__shfl_xor((int)m, o));
         }
-        if (lane == 0) { US[0] = u0; US[1] = ii; MXs = m; }
+        if (lane == 0) { US[0] = u0; MXs = m; }
     }
     // exclusive prefix of the wraps over the chunk: the thread's own frames, wave scan, waves' totals
     uint32_t mine = 0;
@@ -765,7 +767,7 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ 
     __syncthreads();
     uint32_t wraps = incl - mine;
     for (uint32_t k = 0; k < wave; k++) wraps += Wsum[k];
-    const unsigned long long U0 = US[0], I = US[1];
+    const unsigned long long U0 = US[0], I = saw_stats_sum_inc(mode_flag);
 #pragma unroll
     for (uint32_t j = 0; j < FPT; j++) {
         const uint32_t t = FPT * tid + j;
@@ -785,7 +787,7 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ 
     }
     if (blockIdx.x == 0 && tid == 0 && mode_flag) {
         const uint32_t f = (MXs < SAW_EVENTS_MAX_INC && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
-        saw_stats_publish(mode_flag, host_flag, f, I);
+        saw_stats_publish(mode_flag, host_flag, f);
     }
 }
 
@@ -810,12 +812,12 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         return;
     }
     if (blockIdx.x * 64u >= nframes) return;
-    __shared__ unsigned long long Ls[4][64], Us[4][2];
+    __shared__ unsigned long long Ls[4][64], Us[4][1];
     __shared__ uint32_t Ws[4][64], Mx[4];
     const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
     SawPartial *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
     // all loads first (16 independent ones per thread in flight), then the clearing stores
-    unsigned long long lv[SAW_SLOTS / 4], uv[SAW_SLOTS / 4], iv[SAW_SLOTS / 4];
+    unsigned long long lv[SAW_SLOTS / 4], uv[SAW_SLOTS / 4];
     uint32_t wv[SAW_SLOTS / 4];
 #pragma unroll
     for (int k = 0; k < SAW_SLOTS / 4; k++) {
@@ -823,29 +825,28 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         lv[k] = q->L[t];
         wv[k] = q->W[t];
         uv[k] = (t == 0) ? q->U0 : 0ull;
-        iv[k] = (t == 0) ? q->I : 0ull;
     }
     uint32_t mxv[SAW_SLOTS / 4];
 #pragma unroll
     for (int k = 0; k < SAW_SLOTS / 4; k++) mxv[k] = (t == 0) ? p[part + 4 * k].maxinc : 0u;
-    unsigned long long l = 0, u0 = 0, ii = 0;
+    unsigned long long l = 0, u0 = 0;
     uint32_t w = 0, mx = 0;
 #pragma unroll
     for (int k = 0; k < SAW_SLOTS / 4; k++) {
         SawPartial *q = p + part + 4 * k;
-        l += lv[k]; w += wv[k]; u0 += uv[k]; ii += iv[k]; mx = max(mx, mxv[k]);
+        l += lv[k]; w += wv[k]; u0 += uv[k]; mx = max(mx, mxv[k]);
         q->L[t] = 0;
         q->W[t] = 0;
-        if (t == 0) { q->U0 = 0; q->I = 0; q->maxinc = 0; }
+        if (t == 0) { q->U0 = 0; q->maxinc = 0; }
     }
     Ls[part][t] = l;
     Ws[part][t] = w;
-    if (t == 0) { Us[part][0] = u0; Us[part][1] = ii; Mx[part] = mx; }
+    if (t == 0) { Us[part][0] = u0; Mx[part] = mx; }
     __syncthreads();
     if (part == 0) {
         const unsigned long long L = Ls[0][t] + Ls[1][t] + Ls[2][t] + Ls[3][t];
         const unsigned long long U0 = Us[0][0] + Us[1][0] + Us[2][0] + Us[3][0];
-        const unsigned long long I = Us[0][1] + Us[1][1] + Us[2][1] + Us[3][1];
+        const unsigned long long I = saw_stats_sum_inc(mode_flag);
         // W(t): carries of the frames before t (only mod 16 matters) -- exclusive prefix sum over
         // the 64 lanes of this wave (part == 0 is exactly wave 0; lane == t)
         const uint32_t mine = Ws[0][t] + Ws[1][t] + Ws[2][t] + Ws[3][t];
@@ -871,7 +872,7 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         if (blockIdx.x == 0 && t == 0 && mode_flag) {
             const uint32_t m = max(max(Mx[0], Mx[1]), max(Mx[2], Mx[3]));
             const uint32_t fl = (m < SAW_EVENTS_MAX_INC && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
-            saw_stats_publish(mode_flag, host_flag, fl, I);
+            saw_stats_publish(mode_flag, host_flag, fl);
         }
     }
 }
@@ -936,6 +937,15 @@ void saw_rebase_batch_kernel(uint32_t *__restrict__ inc, uint32_t *__restrict__ 
     state0[voice] += tbase * (old - new_inc);
     inc[voice] = new_inc;
     if (hdr) saw_stats_note(hdr, nvoices, old, new_inc);
+}
+// I = sum of all increments, into the scratch header (after the increments were loaded; the header was cleared).
+__global__ __launch_bounds__(256)
+void saw_sum_inc_kernel(const uint32_t *__restrict__ inc, uint32_t n_pad, uint32_t *__restrict__ hdr)
+{
+    unsigned long long s = 0;
+    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < n_pad; v += gridDim.x * 256u) s += inc[v];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(hdr + 4), s);
 }
 // Materialise every phase: state0 += T*inc (the host then resets T to 0).
 __global__ __launch_bounds__(256)
@@ -1190,6 +1200,16 @@ int launch_saw_rebase_batch(uint32_t *d_inc, uint32_t *d_state0, const uint32_t 
     if (npairs == 0) return SMX_OK;
     hipLaunchKernelGGL(saw_rebase_batch_kernel, dim3((npairs + 255) / 256), dim3(256), 0, stream, d_inc,
                        d_state0, d_pairs, npairs, tbase, static_cast<uint32_t *>(d_scratch), n_pad);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_saw_sum_inc(const uint32_t *d_inc, uint32_t n_pad, void *d_scratch, hipStream_t stream)
+{
+    if (!d_scratch) return SMX_OK;
+    uint32_t gx = n_pad / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(saw_sum_inc_kernel, dim3(gx), dim3(256), 0, stream, d_inc, n_pad, static_cast<uint32_t *>(d_scratch));
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

@@ -50,8 +50,10 @@ size_t saw_scratch_bytes(uint32_t max_frames);
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state0, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
                     void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream);
-// leading bytes of the scratch area that hold the formulation flag (zero: stepping form)
+// leading bytes of the scratch area that hold the formulation flag (zero: stepping form) and the bank's sum of
+// increments; after clearing them (new increments) launch_saw_sum_inc recomputes the sum
 size_t saw_scratch_header_bytes();
+int launch_saw_sum_inc(const uint32_t *d_inc, uint32_t n_pad, void *d_scratch, hipStream_t stream);
 int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state0, uint32_t *d_or_bus,
                        uint32_t n_pad, uint32_t nframes, uint32_t tbase, hipStream_t stream);
 // one voice's increment changes at elapsed time tbase; state0 += tbase*inc for all voices
