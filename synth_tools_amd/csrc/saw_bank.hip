@@ -943,7 +943,11 @@ __global__ __launch_bounds__(256)
 void saw_sum_inc_kernel(const uint32_t *__restrict__ inc, uint32_t n_pad, uint32_t *__restrict__ hdr)
 {
     unsigned long long s = 0;
-    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < n_pad; v += gridDim.x * 256u) s += inc[v];
+    const u32x4 *inc4 = reinterpret_cast<const u32x4 *>(inc);          // n_pad is a multiple of 1024
+    for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < n_pad / 4; g += gridDim.x * 256u) {
+        const u32x4 a = inc4[g];
+        s += (unsigned long long)a.x + a.y + a.z + a.w;
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(hdr + 4), s);
 }
@@ -1207,8 +1211,8 @@ int launch_saw_rebase_batch(uint32_t *d_inc, uint32_t *d_state0, const uint32_t 
 int launch_saw_sum_inc(const uint32_t *d_inc, uint32_t n_pad, void *d_scratch, hipStream_t stream)
 {
     if (!d_scratch) return SMX_OK;
-    uint32_t gx = n_pad / 256;
-    if (gx > 1024) gx = 1024;
+    uint32_t gx = n_pad / 1024;
+    if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(saw_sum_inc_kernel, dim3(gx), dim3(256), 0, stream, d_inc, n_pad, static_cast<uint32_t *>(d_scratch));
     SMX_HIP(hipGetLastError());
     return SMX_OK;
