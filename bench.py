@@ -644,7 +644,8 @@ def run_rank(a):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "saw voice bank resident in HBM, %d voices/GPU x %d frame(s)/step "
-                                   "(tick ABI), seeded note bank (splitmix64), all voices on" % (a.voices, a.frames),
+                                   "(%s), seeded note bank (splitmix64), all voices on"
+                                   % (a.voices, a.frames, "tick ABI" if a.frames == 1 else "process() blocks"),
                        "voices_per_gpu": a.voices, "frames_per_step": a.frames,
                        "voices_total": world * a.voices,
                        "baseline_config": "BASELINE configs[1] (int32 phase-accumulator saw voices on 1 MI355X, "
