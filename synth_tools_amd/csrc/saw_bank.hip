@@ -1053,7 +1053,10 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     // 64 frames: direct 78 us, stepping 77 us, wrap events 69 us; 8 Mi voices: 48 / 52 / 49 us)
     static const char *cm = getenv("SMX_SAW_CARRY_MIN_LOG2");           // tuning override
     static const unsigned carry_min_log2 = cm ? (unsigned)atoi(cm) : 30u;
-    const bool big = (unsigned long long)n_pad * nframes >= (1ull << carry_min_log2);
+    // (round 2, with the cheaper event form: 8 Mi voices x 64 frames 42.8 -> 40.6 us as well, x 128 frames 78 -> 70;
+    // 4 Mi voices stay with the direct form: 24.6 vs 31.2 us)
+    const bool big = (unsigned long long)n_pad * nframes >= (1ull << carry_min_log2) ||
+                     (!cm && n_pad >= (1u << 23) && nframes >= 64);
     // (banks from 2^16 voices: 256 Ki voices x 4096 frames 70 -> 44 us, x 16384 frames 260 -> 120 us)
     if (nframes > 32 && n_pad >= (1u << 16) && big && d_scratch && !no_carry) {
         // carry-count formulation: 2 vector ops per voice-sample
