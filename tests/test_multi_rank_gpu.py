@@ -126,3 +126,18 @@ def test_the_test_double_catches_a_broken_spmd_contract(smx):
     assert any(rc != 0 for rc, _, _ in res)
     assert any("SPMD contract" in e or "different collectives" in e for _, _, e in res)
     assert not any("violation_went_unnoticed" in o for _, o, _ in res if o)
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_plain_c_host_shards_a_bank_over_forked_processes(smx, nranks):
+    """tests/c/test_multi_rank.c: fork before any GPU call, the unique id over pipes, smx_bank_comm_init, sync and
+    pipelined smx_bank_run on every rank; all ranks hold the same samples, and they are the samples of the whole
+    bank in one process.  The header's multi-GPU section used from C, no Python in the data path."""
+    fake = _fake_rccl()
+    exe = os.path.join(os.path.dirname(HERE), "host", "test_multi_rank.dynamic.host.elf")
+    if fake is None or not os.path.exists(exe):
+        pytest.skip("needs hipcc (RCCL test double) and the host programs (make -C host)")
+    p = subprocess.run([exe, str(nranks), "1"], env=dict(os.environ, LD_PRELOAD=fake), capture_output=True, text=True,
+                       timeout=200)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "%d ranks ok" % nranks in p.stderr
