@@ -130,7 +130,7 @@ struct smx_bank {
     bool comm_pending[NBUS] = {};                // an all-reduce was issued on bus[i] and not waited for
     int ev_owner[NBUS] = {};                     // ev_comm[ev_owner[i]] completes after bus[i]'s all-reduce
     // All-reduces are requested per block but issued in groups (fewer, larger collectives): a
-    // request is queued and the queue is flushed as ONE grouped RCCL launch when it holds NBUS/2
+    // request is queued and the queue is flushed as ONE all-reduce over the contiguous slots when it holds comm_group
     // blocks, or as soon as somebody needs a result (fetch, sync, buffer reuse).
     int ar_queue[NBUS] = {};                     // bus indices with a requested, not yet issued sum
     int ar_frames[NBUS] = {};
