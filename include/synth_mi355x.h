@@ -166,6 +166,15 @@ int smx_bank_timer_stop(smx_bank *b, float *ms);
 int smx_comm_unique_id(uint8_t id[SMX_UNIQUE_ID_BYTES]);   /* rank 0; hand the bytes to the other ranks */
 int smx_bank_comm_init(smx_bank *b, int rank, int nranks,
                        const uint8_t id[SMX_UNIQUE_ID_BYTES]);
+/* Note routing over the shards ("note-on routing is host-side").  smx_bank_shard declares this bank the
+ * shard [first_voice, first_voice + n) of a global bank of total_voices voices (equal shards of a multiple of 64
+ * voices: first_voice = rank x n, total_voices = ranks x n).  From then on smx_bank_note_on / _note_off /
+ * _midi_event(s) run the reference's allocator (linux/synth.c:145-165: first free voice, steal voice 0 when full,
+ * stray note-off silences voice 0) over the WHOLE global bank on every rank -- every rank is given the same events
+ * in the same order, so every rank takes the same decisions -- and each rank applies to its device arrays only what
+ * falls into its own range.  smx_bank_load(inc) on a sharded bank is collective: the ranks exchange which of their
+ * voices are free.  Call it after smx_bank_comm_init, on every rank. */
+int smx_bank_shard(smx_bank *b, uint32_t first_voice, uint32_t total_voices);
 /* Ranks the communicator really spans (ncclCommCount); 0 without a communicator. */
 int smx_bank_comm_ranks(const smx_bank *b);
 /* All-reduce (sum, int32) of the last block's bus across ranks, in place in device memory, on

@@ -106,6 +106,7 @@ ABI = [
     ("smx_comm_unique_id", C.c_int, [_u8]),
     ("smx_bank_comm_init", C.c_int, [_P, C.c_int, C.c_int, _u8]),
     ("smx_bank_allreduce_async", C.c_int, [_P, C.c_int]),
+    ("smx_bank_shard", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("smx_bank_comm_ranks", C.c_int, [_P]),
     ("smx_bank_set_comm_group", C.c_int, [_P, C.c_int]),
     ("smx_bank_comm_stats", C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
@@ -316,6 +317,9 @@ class SawBank:
 
     def allreduce_async(self, n):
         _check(lib().smx_bank_allreduce_async(self._h, n), "smx_bank_allreduce_async")
+
+    def shard(self, first_voice, total_voices):
+        _check(lib().smx_bank_shard(self._h, first_voice, total_voices), "smx_bank_shard")
 
     def comm_ranks(self):
         return lib().smx_bank_comm_ranks(self._h)

@@ -5,6 +5,16 @@
 #include <rccl/rccl.h>
 #include <unordered_map>
 
+#define SMX_NCCL(expr)                                                         \
+    do {                                                                       \
+        ncclResult_t r_ = (expr);                                              \
+        if (r_ != ncclSuccess) {                                               \
+            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
+                      ncclGetErrorString(r_));                                 \
+            return SMX_E_COMM;                                                 \
+        }                                                                      \
+    } while (0)
+
 namespace smx {
 
 // First-free search over N voices in O(log64 N): the reference scans its 64
@@ -21,8 +31,10 @@ public:
             levels_.emplace_back(words, 0ull);
             bits = words;
         } while (bits > 1);
-        if (all_free)
-            for (uint32_t v = 0; v < n; v++) set_leaf_only(v);
+        if (all_free) {
+            std::fill(levels_[0].begin(), levels_[0].end(), ~0ull);
+            if (n & 63) levels_[0].back() = (1ull << (n & 63)) - 1ull;     // no voices beyond n
+        }
         rebuild_summaries();
     }
     void load(const uint32_t *inc, uint32_t n)
@@ -47,6 +59,14 @@ public:
                 is_free = any;
             }
         }
+    }
+    // the map's leaf words (bit v of word v/64 = voice v is free), for exchanging shards' maps between ranks
+    const uint64_t *leaf_words() const { return levels_[0].data(); }
+    size_t n_leaf_words() const { return levels_[0].size(); }
+    void load_leaf_words(size_t first_word, const uint64_t *w, size_t nwords)
+    {
+        for (size_t i = 0; i < nwords; i++) levels_[0][first_word + i] = w[i];
+        rebuild_summaries();
     }
     // index of the first free voice, or -1
     int64_t first_free() const
@@ -141,6 +161,11 @@ struct smx_bank {
     int comm_count = 0;                          // ncclCommCount: ranks the communicator really spans
     unsigned long long ar_launches = 0, ar_blocks = 0;   // collectives issued / block sums they carried
     int note2voice[128];
+    // Sharded bank (smx_bank_shard): this bank holds voices [shard_first, shard_first + n) of a global bank of
+    // shard_total voices.  Every rank runs the reference's allocator (linux/synth.c:145-165) over the WHOLE global
+    // bank -- the same MIDI events in the same order give the same decisions everywhere -- and applies to its
+    // device arrays only what falls into its own range: note2voice[] and free_map are then in global voice numbers.
+    uint32_t shard_first = 0, shard_total = 0;   // shard_total == 0: not sharded (free_map covers n voices)
     smx::FreeMap free_map;
     // smx_bank_midi_events: (voice, increment) pairs of one batch, staged in pinned memory (two
     // slots, so the host can fill one while the copy of the other is in flight) and a device copy
@@ -160,6 +185,15 @@ static void bank_form_unpin(smx_bank *b)
 {
     b->form_seen = 0xFFFFFFFFu;
     b->form_stable = 0;
+}
+
+// Does the (global) voice number belong to this bank?  -> its local index
+static inline bool bank_owns(const smx_bank *b, uint32_t v, uint32_t *local)
+{
+    if (!b->shard_total) { *local = v; return true; }
+    if (v < b->shard_first || v - b->shard_first >= b->n) return false;
+    *local = v - b->shard_first;
+    return true;
 }
 
 static int bank_ensure_bus(smx_bank *b, uint32_t n)
@@ -293,6 +327,62 @@ static int bank_materialize(smx_bank *b)
     return SMX_OK;
 }
 
+// A sharded bank got new increments: the ranks exchange which of their voices are free, so that every rank's
+// copy of the global allocator sees the whole bank (ncclAllGather of the shards' free-bit words; n is a multiple
+// of 64 on a sharded bank, so a shard is whole words).
+static int bank_exchange_free_maps(smx_bank *b, const uint32_t *inc)
+{
+    const size_t w = b->n / 64;                               // words per shard
+    std::vector<uint64_t> mine(w, 0ull);
+    for (uint32_t v = 0; v < b->n; v++)
+        if (inc[v] == 0) mine[v >> 6] |= 1ull << (v & 63);
+    const int nr = b->comm ? b->nranks : 1;
+    if ((size_t)nr * w != b->shard_total / 64 || b->shard_first != (uint32_t)(b->comm ? b->rank : 0) * b->n) {
+        set_error("smx_bank_load: a sharded bank needs its communicator, equal shards (total = ranks x voices) and shard r at r x voices");
+        return SMX_E_STATE;
+    }
+    std::vector<uint64_t> all((size_t)nr * w);
+    if (nr == 1) {
+        all = mine;
+    } else {
+        uint64_t *d_send = nullptr, *d_recv = nullptr;
+        SMX_HIP(hipMalloc((void **)&d_send, w * 8));
+        SMX_HIP(hipMalloc((void **)&d_recv, (size_t)nr * w * 8));
+        SMX_HIP(hipMemcpy(d_send, mine.data(), w * 8, hipMemcpyHostToDevice));
+        SMX_NCCL(ncclAllGather(d_send, d_recv, w * 8, ncclUint8, b->comm, b->comm_stream));
+        SMX_HIP(hipStreamSynchronize(b->comm_stream));
+        SMX_HIP(hipMemcpy(all.data(), d_recv, (size_t)nr * w * 8, hipMemcpyDeviceToHost));
+        SMX_HIP(hipFree(d_send));
+        SMX_HIP(hipFree(d_recv));
+    }
+    b->free_map.load_leaf_words(0, all.data(), all.size());
+    return SMX_OK;
+}
+
+// Declare this bank the shard [first_voice, first_voice + n) of a global bank of total_voices voices.
+extern "C" int smx_bank_shard(smx_bank *b, uint32_t first_voice, uint32_t total_voices)
+{
+    if (!b || (b->n & 63) || total_voices < b->n || first_voice > total_voices - b->n || (first_voice % b->n) ||
+        (total_voices % b->n)) {
+        set_error("smx_bank_shard: first=%u total=%u for a bank of %u voices (equal shards, a multiple of 64 voices each)",
+                  first_voice, total_voices, b ? b->n : 0);
+        return SMX_E_ARG;
+    }
+    SMX_HIP(hipSetDevice(b->device));
+    SMX_HIP(hipStreamSynchronize(b->stream));
+    b->shard_first = first_voice;
+    b->shard_total = total_voices;
+    memset(b->note2voice, 0, sizeof(b->note2voice));
+    // the allocator starts from what this shard holds now (a fresh bank: every voice free) and "unknown = free"
+    // for the others; a later smx_bank_load(inc) exchanges the real maps
+    std::vector<uint32_t> inc(b->n);
+    SMX_HIP(hipMemcpy(inc.data(), b->d_inc, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    b->free_map.reset(total_voices, true);
+    for (uint32_t v = 0; v < b->n; v++)
+        if (inc[v]) b->free_map.set_free(first_voice + v, false);
+    return SMX_OK;
+}
+
 extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *state)
 {
     if (!b) { set_error("smx_bank_load: null bank"); return SMX_E_ARG; }
@@ -302,7 +392,12 @@ extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *s
     SMX_HIP(hipStreamSynchronize(b->stream));
     if (inc) {
         SMX_HIP(hipMemcpy(b->d_inc, inc, (size_t)b->n * 4, hipMemcpyHostToDevice));
-        b->free_map.load(inc, b->n);
+        if (b->shard_total) {
+            rv = bank_exchange_free_maps(b, inc);            // collective: every rank loads its shard
+            if (rv) return rv;
+        } else {
+            b->free_map.load(inc, b->n);
+        }
         // new increments: the statistic that picks the long-block form is void (stepping until the
         // next long block has measured the new bank)
         if (b->d_scratch) {
@@ -350,13 +445,16 @@ extern "C" int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state)
 // next block, that also rebases the voice's stored phase so that state0 + elapsed*inc stays
 // continuous ("note_on does not reset the phase", linux/synth.c:156-160).  No host sync per
 // event: the JACK thread can apply a burst of MIDI events and launch the block behind them.
+// (v is the allocator's voice number: global on a sharded bank, where only the owner touches the device.)
 static int bank_set_inc(smx_bank *b, uint32_t v, uint32_t inc)
 {
+    b->free_map.set_free(v, inc == 0);
+    uint32_t local;
+    if (!bank_owns(b, v, &local)) return SMX_OK;
     SMX_HIP(hipSetDevice(b->device));
-    int rv = smx::launch_saw_rebase(b->d_inc, b->d_state0, v, inc, b->elapsed, b->d_scratch, b->n_pad, b->stream);
+    int rv = smx::launch_saw_rebase(b->d_inc, b->d_state0, local, inc, b->elapsed, b->d_scratch, b->n_pad, b->stream);
     if (rv) return rv;
     bank_form_unpin(b);
-    b->free_map.set_free(v, inc == 0);
     return SMX_OK;
 }
 
@@ -386,15 +484,6 @@ extern "C" int smx_bank_note_off(smx_bank *b, int note)
 // runs its all-reduces in order, so waiting for a YOUNGER one covers buffer i too: the wait
 // is taken on the youngest all-reduce that is at least NBUS/2 blocks old, which retires half
 // the ring at once -- one cross-stream barrier per NBUS/2 blocks in steady state.
-#define SMX_NCCL(expr)                                                         \
-    do {                                                                       \
-        ncclResult_t r_ = (expr);                                              \
-        if (r_ != ncclSuccess) {                                               \
-            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
-                      ncclGetErrorString(r_));                                 \
-            return SMX_E_COMM;                                                 \
-        }                                                                      \
-    } while (0)
 
 // Issue every queued bus sum on the comm stream, ordered after all kernels enqueued so far.
 // The queue holds consecutive ring slots (smx_bank_allreduce_async flushes before a gap or the
@@ -560,10 +649,12 @@ extern "C" int smx_bank_midi_events(smx_bank *b, const uint8_t *msgs3, size_t n_
     uint32_t npairs = 0;
     b->ev_net.clear();
     auto put = [&](uint32_t v, uint32_t inc) {
-        auto it = b->ev_net.find(v);
-        if (it == b->ev_net.end()) { b->ev_net.emplace(v, npairs); pairs[2 * npairs] = v; pairs[2 * npairs + 1] = inc; npairs++; }
+        b->free_map.set_free(v, inc == 0);                   // the (global) allocator sees every event
+        uint32_t local;
+        if (!bank_owns(b, v, &local)) return;                // another rank's voice
+        auto it = b->ev_net.find(local);
+        if (it == b->ev_net.end()) { b->ev_net.emplace(local, npairs); pairs[2 * npairs] = local; pairs[2 * npairs + 1] = inc; npairs++; }
         else pairs[2 * it->second + 1] = inc;
-        b->free_map.set_free(v, inc == 0);
     };
     for (size_t i = 0; i < n_events; i++) {
         const uint8_t *m = msgs3 + 3 * i;

@@ -3,7 +3,7 @@
 // The one-GPU test box cannot run the product's multi-rank path: RCCL refuses two ranks on one device.  This
 // library is LD_PRELOADed in front of librccl by tests/test_multi_rank_gpu.py so that 2..4 PROCESSES sharing the
 // one GPU can drive libsynth_mi355x.so's sharded bank exactly as they would on 2..4 GPUs: it implements the seven
-// entry points the product calls (ncclGetUniqueId, ncclCommInitRank, ncclCommCount, ncclAllReduce,
+// entry points the product calls (ncclGetUniqueId, ncclCommInitRank, ncclCommCount, ncclAllReduce, ncclAllGather,
 // ncclGroupStart/End, ncclCommDestroy, ncclGetErrorString) over a POSIX shared-memory segment.
 //   * ncclAllReduce(int32, sum) is stream-ordered like the real one: it waits for the stream, stages the operand
 //     through shared memory, meets the other ranks at a barrier, sums, and writes the result back in place.
@@ -155,6 +155,30 @@ ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, n
     barrier(c);                                             // everybody has read every operand
     if (hipMemcpy(recvbuff, sum, count * 4, hipMemcpyHostToDevice) != hipSuccess) die("H2D failed");
     free(sum);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm,
+                           hipStream_t stream)
+{
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    Shm *s = c->shm;
+    if (datatype != ncclUint8) die("only byte all-gathers are used by the product");
+    const size_t words = (sendcount + 3) / 4;
+    if (sendcount == 0 || words > MAX_COUNT) die("all-gather size out of range");
+    if (hipStreamSynchronize(stream) != hipSuccess) die("hipStreamSynchronize failed");
+    if (hipMemcpy(s->buf[c->rank], sendbuff, sendcount, hipMemcpyDeviceToHost) != hipSuccess) die("D2H failed");
+    s->count[c->rank] = sendcount | (1ull << 40);          // tagged: an all-gather, not an all-reduce
+    const unsigned long long my_seq = s->seq[c->rank].fetch_add(1) + 1;
+    barrier(c);
+    for (int r = 0; r < c->nranks; r++) {
+        if (s->count[r] != (sendcount | (1ull << 40))) die("ranks issue different collectives: the SPMD contract is broken");
+        if (s->seq[r].load() != my_seq) die("ranks are at different collectives");
+    }
+    for (int r = 0; r < c->nranks; r++)
+        if (hipMemcpy(static_cast<char *>(recvbuff) + (size_t)r * sendcount, s->buf[r], sendcount, hipMemcpyHostToDevice) != hipSuccess)
+            die("H2D failed");
+    barrier(c);
     return ncclSuccess;
 }
 

@@ -12,6 +12,59 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def allocator_mode(rank, world, per, bank, orc, tab, oracle, synthetic):
+    """The reference's allocator (linux/synth.c:145-165) over the GLOBAL bank, replicated on every rank
+    (smx_bank_shard): the same MIDI stream on every rank; compared with the oracle's allocator over one array of
+    world * per voices -- the reduced bus of every block, and at the end this rank's slice of inc[] / state[]."""
+    total = world * per
+    bank.load(np.zeros(per, np.uint32), np.zeros(per, np.uint32))     # a fresh bank (main() had loaded a shard)
+    bank.shard(rank * per, total)
+    rng = np.random.default_rng(4711)                       # the SAME stream on every rank
+    g_inc = np.zeros(total, np.uint32)
+    g_st = np.zeros(total, np.uint32)
+    n2v = np.zeros(128, np.int32)
+    checks = 0
+
+    def block(nf):
+        bus, _ = bank.run(nf)
+        obus, _ = oracle.synth_run(orc, g_inc, g_st, nf, want_vec=False)
+        assert np.array_equal(bus, obus), "bus"
+
+    # (a) a fresh bank: note-ons fill the global bank in voice order, across the shard boundaries
+    for k in range(40):
+        note = int(rng.integers(0, 128))
+        if rng.random() < 0.7:
+            bank.note_on(note); orc.orc_note_on(n2v, g_inc, total, note)
+        else:
+            bank.note_off(note); orc.orc_note_off(n2v, g_inc, total, note)       # incl. stray note-offs -> voice 0
+        if k % 5 == 4:
+            block(64); checks += 1
+    # (b) a loaded bank (collective load: the ranks exchange their free maps), a few free voices in every shard
+    g_inc[:], g_st[:] = synthetic.saw_bank(total, 0x5EED0A11, tab, active_fraction=0.97)
+    n2v[:] = 0
+    bank.shard(rank * per, total)                           # resets the note table, as a fresh synth_init would
+    bank.load(g_inc[rank * per:(rank + 1) * per], g_st[rank * per:(rank + 1) * per])
+    block(64); checks += 1
+    # batches of events (one copy + one kernel per block on the owner ranks) until the bank is full, then beyond:
+    # the allocator steals global voice 0 (rank 0's) on every further note-on
+    saw_full = False
+    for blk in range(12):
+        ev = np.zeros((40, 3), np.uint8)
+        ev[:, 0] = np.where(rng.random(40) < 0.75, 0x90, 0x80)
+        ev[:, 1] = rng.integers(0, 128, 40)
+        ev[:, 2] = np.where(rng.random(40) < 0.9, 100, 0)    # velocity 0 = note-off
+        bank.midi_events(ev)
+        for m in ev:
+            saw_full = saw_full or not np.any(g_inc == 0)    # a note-on into a full bank steals global voice 0
+            orc.orc_midi_event(n2v, g_inc, total, np.ascontiguousarray(m), 3)
+        block(int(rng.choice([1, 16, 64]))); checks += 1
+    full = saw_full
+    inc, st = bank.read()
+    assert np.array_equal(inc, g_inc[rank * per:(rank + 1) * per]), "inc slice"
+    assert np.array_equal(st, g_st[rank * per:(rank + 1) * per]), "state slice"
+    print(json.dumps({"rank": rank, "ranks_seen": bank.comm_ranks(), "checks": checks, "bank_filled_up": bool(full)}))
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     device = int(os.environ.get("SMX_TEST_DEVICE", os.environ.get("LOCAL_RANK", "0")))
@@ -34,6 +87,12 @@ def main():
     def expect(nf):
         return oracle.synth_run(orc, all_inc, all_st, nf)
 
+    if os.environ.get("SMX_TEST_ALLOCATOR"):
+        allocator_mode(rank, world, per, bank, orc, tab, oracle, synthetic)
+        rdzv.barrier()
+        bank.close()
+        rdzv.close()
+        return
     if os.environ.get("SMX_TEST_VIOLATE"):
         # the SPMD contract broken on purpose: only rank 0 fetches in the middle of a group, so the ranks would
         # issue different collectives (3 blocks + 5 blocks vs 8 blocks).  With the test double this aborts.

@@ -141,3 +141,22 @@ def test_plain_c_host_shards_a_bank_over_forked_processes(smx, nranks):
                        timeout=200)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "%d ranks ok" % nranks in p.stderr
+
+
+@pytest.mark.parametrize("world,voices", [(1, 128), (2, 128), (3, 64), (2, 4096)])
+def test_global_allocator_over_sharded_banks(smx, world, voices):
+    """"note-on routing is host-side".  smx_bank_shard: every rank runs the reference's allocator over
+    the whole global bank (first free voice in GLOBAL voice order, steal voice 0 when the global bank is full, a stray
+    note-off silences global voice 0) and applies only its own voices; a collective load exchanges the free maps.
+    Against the oracle's allocator over ONE array of world x voices voices: every block's reduced bus, and each
+    rank's slice of the final inc[] / state[]."""
+    fake = _fake_rccl()
+    if fake is None:
+        pytest.skip("hipcc not available to build the RCCL test double")
+    res = _run(world, [0] * world, voices=voices, preload=fake, extra_env={"SMX_TEST_ALLOCATOR": "1"})
+    for rc, o, e in res:
+        assert rc == 0, e[-3000:]
+        r = json.loads(o.strip().splitlines()[-1])
+        assert r["ranks_seen"] == world and r["checks"] >= 20
+        if voices <= 128:
+            assert r["bank_filled_up"]                       # so the steal-voice-0 path ran
