@@ -18,6 +18,12 @@
  *   SYNTH_VOICES=1048576 synth.dynamic.host.elf  real JACK, N-voice bank path
  *   SYNTH_FILL=1                                  the bank starts with every voice sounding
  *   SYNTH_PIPELINE=1 ...                         bank path returns block k-1 while k computes
+ *   SYNTH_RANKS=8 SYNTH_VOICES=8388608 ...       the bank sharded over 8 GPUs: 7 helper processes (forked before any
+ *                                                GPU call) hold the other shards; this process stays the only JACK
+ *                                                client, forwards every block's MIDI events and frame count to the
+ *                                                helpers over pipes, and the library sums the buses (RCCL).
+ *                                                SYNTH_DEVICES=0,1,... maps ranks to HIP devices (default: rank r ->
+ *                                                device r)
  *   SYNTH_FAKE_PERIOD_US=1333 ... --fake-jack    pace the scripted callbacks like a sound card
  *   synth.dynamic.host.elf --fake-jack NBLOCKS NFRAMES EVENTS.bin OUT.f32
  *       EVENTS.bin: records {u32 block; u8 size; u8 bytes[3]} delivered to
@@ -31,6 +37,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <sys/types.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -81,13 +88,49 @@ static int fake_midi_event_get(jack_midi_event_t *e, void *b, uint32_t i) { (voi
 static struct synth synth;               /* linux/synth.c:208 */
 static smx_bank *bank;                   /* SYNTH_VOICES > 64 */
 
+/* SYNTH_RANKS > 1: this process is rank 0 and the only JACK client; helper[r] is the write end of rank r's pipe. */
+static int n_ranks = 1, my_rank = 0;
+static int helper[8];
+struct rank_cmd { uint32_t nframes, nev; };          /* then 3 * nev bytes of events; nframes 0: events only */
+
+static void write_all(int fd, const void *buf, size_t n) {
+    const uint8_t *p = buf;
+    while (n) {
+        ssize_t w = write(fd, p, n);
+        if (w < 0) { if (errno == EINTR) continue; LOG("synth: a helper rank is gone\n"); exit(1); }
+        p += w; n -= (size_t)w;
+    }
+}
+static int read_all(int fd, void *buf, size_t n) {      /* 0 on EOF */
+    uint8_t *p = buf;
+    while (n) {
+        ssize_t r = read(fd, p, n);
+        if (r == 0) return 0;
+        if (r < 0) { if (errno == EINTR) continue; return 0; }
+        p += r; n -= (size_t)r;
+    }
+    return 1;
+}
+static void to_helpers(uint32_t nframes, const uint8_t *ev3, uint32_t nev) {
+    struct rank_cmd c = { nframes, nev };
+    for (int r = 1; r < n_ranks; r++) {
+        write_all(helper[r], &c, sizeof c);
+        if (nev) write_all(helper[r], ev3, 3u * nev);
+    }
+}
+static int device_of(int rank) {
+    const char *d = getenv("SYNTH_DEVICES");
+    for (int r = 0; d && r < rank; r++) { d = strchr(d, ','); if (d) d++; }
+    return d ? atoi(d) : rank;
+}
+
 /* SYNTH_FILL=1: start with every voice of the bank sounding (notes 21..108 spread over the voices,
  * scattered phases) instead of silence -- what a latency measurement of a full bank needs. */
-static void bank_fill(smx_bank *b, uint32_t n) {
+static void bank_fill(smx_bank *b, uint32_t first, uint32_t n) {
     uint32_t *inc = malloc((size_t)n * 4), *st = malloc((size_t)n * 4);
     ASSERT(inc && st);
     for (uint32_t v = 0; v < n; v++) {
-        uint32_t h = v * 2654435761u;
+        uint32_t h = (first + v) * 2654435761u;          /* by GLOBAL voice number: the same bank however it is sharded */
         /* SYNTH_FILL=worst: every voice wraps 12 times per 64 frames (increment 12/64 of 2^32), the
            bank on which locating the wraps costs most; anything else: piano range */
         const char *fill = getenv("SYNTH_FILL");
@@ -97,6 +140,36 @@ static void bank_fill(smx_bank *b, uint32_t n) {
     }
     ASSERT(0 == smx_bank_load(b, inc, st));
     free(inc); free(st);
+}
+
+/* The N-voice bank of this rank (SYNTH_VOICES > 64): its shard of the voices, the communicator, the options. */
+static void setup_bank(uint32_t voices, const uint8_t *id) {
+    if (voices <= 64) return;
+    const uint32_t per = voices / (uint32_t)n_ranks;
+    ASSERT(n_ranks == 1 || (voices % (uint32_t)n_ranks == 0 && per % 64 == 0));
+    ASSERT((bank = smx_bank_create(per, device_of(my_rank))));
+    if (n_ranks > 1) {
+        ASSERT(0 == smx_bank_comm_init(bank, my_rank, n_ranks, id));
+        ASSERT(0 == smx_bank_shard(bank, (uint32_t)my_rank * per, voices));    /* the allocator spans all ranks */
+    }
+    if (getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
+    if (getenv("SYNTH_FORM_STEPPING")) ASSERT(0 == smx_bank_set_block_form(bank, SMX_FORM_STEPPING));
+    if (getenv("SYNTH_FILL")) bank_fill(bank, (uint32_t)my_rank * per, per);
+}
+
+/* A helper rank: no JACK, no stdin -- it does what rank 0 tells it, block by block, and leaves when the pipe closes. */
+static void helper_loop(int fd, uint32_t voices) {
+    uint8_t id[SMX_UNIQUE_ID_BYTES];
+    if (!read_all(fd, id, sizeof id)) _exit(0);
+    setup_bank(voices, id);
+    static uint8_t ev[3 * 4096];
+    struct rank_cmd c;
+    while (read_all(fd, &c, sizeof c)) {
+        ASSERT(c.nev <= 4096);
+        if (c.nev) { if (!read_all(fd, ev, 3u * c.nev)) break; ASSERT(0 == smx_bank_midi_events(bank, ev, c.nev)); }
+        if (c.nframes) ASSERT(0 == smx_bank_run(bank, NULL, NULL, (int)c.nframes));
+    }
+    _exit(0);
 }
 static jack_port_t *midi_in, *audio_out; /* linux/synth.c:214-221 */
 
@@ -111,14 +184,14 @@ static inline void process_midi(jack_nframes_t nframes) {        /* linux/synth.
         const uint8_t *msg = event.buffer;
         if (!bank) { synth_midi_event(&synth, msg, event.size); continue; }
         if (event.size != 3) continue;           /* linux/synth.c:236: only 3-byte events */
-        if (nbatch == 4096) { ASSERT(0 == smx_bank_midi_events(bank, batch, nbatch)); nbatch = 0; }
+        if (nbatch == 4096) { to_helpers(0, batch, 4096); ASSERT(0 == smx_bank_midi_events(bank, batch, nbatch)); nbatch = 0; }
         memcpy(batch + 3 * nbatch++, msg, 3);
     }
-    if (nbatch) ASSERT(0 == smx_bank_midi_events(bank, batch, nbatch));
+    if (nbatch) { to_helpers(0, batch, (uint32_t)nbatch); ASSERT(0 == smx_bank_midi_events(bank, batch, nbatch)); }
 }
 static inline void process_audio(jack_nframes_t nframes) {       /* linux/synth.c:261-276 */
     jack_default_audio_sample_t *dst = jack.port_get_buffer(audio_out, nframes);
-    if (bank) ASSERT(0 == smx_bank_run(bank, dst, NULL, (int)nframes));
+    if (bank) { to_helpers(nframes, NULL, 0); ASSERT(0 == smx_bank_run(bank, dst, NULL, (int)nframes)); }
     else      synth_run(&synth, dst, (int)nframes);
 }
 static int process(jack_nframes_t nframes, void *arg) {          /* linux/synth.c:277-282 */
@@ -155,6 +228,31 @@ static void read_fixed(int fd, uint8_t *buf, size_t n) {         /* assert_read,
 int main(int argc, char **argv) {
     const char *voices_env = getenv("SYNTH_VOICES");
     uint32_t voices = voices_env ? (uint32_t)strtoul(voices_env, NULL, 0) : 64;
+    uint8_t id[SMX_UNIQUE_ID_BYTES] = {0};
+    if (getenv("SYNTH_RANKS") && voices > 64) {
+        /* fork the helper ranks FIRST: no process may have touched the GPU when it forks */
+        n_ranks = atoi(getenv("SYNTH_RANKS"));
+        ASSERT(n_ranks >= 1 && n_ranks <= 8);
+        for (int r = 1; r < n_ranks; r++) {
+            int fd[2];
+            ASSERT(0 == pipe(fd));
+            pid_t pid = fork();
+            ASSERT(pid >= 0);
+            if (pid == 0) {
+                close(fd[1]);
+                for (int k = 1; k < r; k++) close(helper[k]);      /* the other helpers' pipes are not ours */
+                close(0);
+                my_rank = r;
+                helper_loop(fd[0], voices);
+            }
+            close(fd[0]);
+            helper[r] = fd[1];
+        }
+        if (n_ranks > 1) {
+            ASSERT(0 == smx_comm_unique_id(id));
+            for (int r = 1; r < n_ranks; r++) write_all(helper[r], id, sizeof id);
+        }
+    }
 
     if (argc >= 2 && !strcmp(argv[1], "--fake-jack")) {
         ASSERT(argc == 6);
@@ -175,10 +273,7 @@ int main(int argc, char **argv) {
         jack.midi_event_get = fake_midi_event_get;
         midi_in = FAKE_MIDI_PORT;
         audio_out = FAKE_AUDIO_PORT;
-        if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
-        if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
-        if (bank && getenv("SYNTH_FORM_STEPPING")) ASSERT(0 == smx_bank_set_block_form(bank, SMX_FORM_STEPPING));
-        if (bank && getenv("SYNTH_FILL")) bank_fill(bank, (uint32_t)voices);
+        setup_bank(voices, id);
         synth_init(&synth);
         FILE *out = fopen(argv[5], "wb");
         ASSERT(out);
@@ -227,10 +322,7 @@ int main(int argc, char **argv) {
         ASSERT(client);
         ASSERT(midi_in = jack.port_register(client, "midi_in", JACK_DEFAULT_MIDI_TYPE, JackPortIsInput, 0));
         ASSERT(audio_out = jack.port_register(client, "audio_out", JACK_DEFAULT_AUDIO_TYPE, JackPortIsOutput, 0));
-        if (voices > 64) ASSERT((bank = smx_bank_create(voices, 0)));
-        if (bank && getenv("SYNTH_PIPELINE")) ASSERT(0 == smx_bank_set_block_mode(bank, SMX_BLOCK_PIPELINED));
-        if (bank && getenv("SYNTH_FORM_STEPPING")) ASSERT(0 == smx_bank_set_block_form(bank, SMX_FORM_STEPPING));
-        if (bank && getenv("SYNTH_FILL")) bank_fill(bank, (uint32_t)voices);
+        setup_bank(voices, id);
         synth_init(&synth);
         jack.set_process_callback(client, process, 0);
         ASSERT(!mlockall(MCL_CURRENT | MCL_FUTURE));

@@ -160,3 +160,54 @@ def test_global_allocator_over_sharded_banks(smx, world, voices):
         assert r["ranks_seen"] == world and r["checks"] >= 20
         if voices <= 128:
             assert r["bank_filled_up"]                       # so the steal-voice-0 path ran
+
+
+@pytest.mark.parametrize("ranks,fill,pipeline", [(2, False, False), (4, True, False), (2, True, True)])
+def test_jack_host_program_over_several_ranks(smx, orc, tmp_path, ranks, fill, pipeline):
+    """host/synth.dynamic.host.elf with SYNTH_RANKS: the one JACK client (fake JACK here) forks helper ranks before
+    any GPU call, forwards every block's MIDI events and frame count over pipes, each rank runs its shard of the
+    bank with the GLOBAL allocator, the library sums the buses.  The rendered audio must be what the oracle renders
+    for ONE bank of all the voices -- the same file a single-process run of the same bank writes."""
+    import struct
+    fake = _fake_rccl()
+    exe = os.path.join(os.path.dirname(HERE), "host", "synth.dynamic.host.elf")
+    if fake is None or not os.path.exists(exe):
+        pytest.skip("needs hipcc (RCCL test double) and the host programs (make -C host)")
+    import oracle
+    voices = 64 * ranks * 3
+    events = [(0, [0x90, 60, 100]), (0, [0x90, 64, 100]), (2, [0x90, 67, 90]), (4, [0x80, 64, 0]), (5, [0x80, 99, 0]),
+              (6, [0x90, 72, 1])] + [(8, [0x90, 20 + (k % 100), 100]) for k in range(voices + 30)] + \
+             [(10, [0x80, 30 + k, 0]) for k in range(0, 60, 2)] + [(11, [0x90, 55, 100])]
+    ev, out = tmp_path / "ev.bin", tmp_path / "out.f32"
+    with open(ev, "wb") as f:
+        for blk, msg in events:
+            f.write(struct.pack("<IB3s", blk, len(msg), bytes(msg)))
+    nblocks = 14
+    env = dict(os.environ, SYNTH_VOICES=str(voices), SYNTH_RANKS=str(ranks), SYNTH_DEVICES=",".join(["0"] * ranks),
+               LD_PRELOAD=fake)
+    if fill:
+        env["SYNTH_FILL"] = "1"
+    if pipeline:
+        env["SYNTH_PIPELINE"] = "1"
+    r = subprocess.run([exe, "--fake-jack", str(nblocks), "64", str(ev), str(out)], env=env, stdin=subprocess.DEVNULL,
+                       capture_output=True, timeout=200)
+    assert r.returncode == 1, r.stderr.decode()[-2000:]       # EOF on stdin -> exit(1), linux/synth.c:305-310
+    got = np.fromfile(out, np.float32)
+    if fill:
+        v = np.arange(voices, dtype=np.uint64)
+        h = (v * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+        inc = np.array([orc.orc_note_to_inc(21 + int((x >> np.uint64(12)) % np.uint64(88))) for x in h], np.uint32)
+        st = ((h * np.uint64(40503) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    else:
+        inc, st = np.zeros(voices, np.uint32), np.zeros(voices, np.uint32)
+    n2v = np.zeros(128, np.int32)
+    want = []
+    for blk in range(nblocks):
+        for b, msg in events:
+            if b == blk:
+                orc.orc_midi_event(n2v, inc, voices, np.array(msg, np.uint8), 3)
+        want.append(oracle.synth_run(orc, inc, st, 64)[1])
+    want = np.concatenate(want)
+    if pipeline:                                              # one block late, silence first
+        want = np.concatenate([np.zeros(64, np.float32), want[:-64]])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
