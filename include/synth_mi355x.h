@@ -146,7 +146,8 @@ int smx_bank_next_block_form(smx_bank *b);
 int   smx_bank_run_async(smx_bank *b, int n);
 void *smx_bank_bus_dev(smx_bank *b);     /* device int32[n] of the last block */
 int   smx_bank_sync(smx_bank *b);
-/* sum_tick_square (linux/synth.c:182-195) for n frames; vec host float[n]. */
+/* sum_tick_square (linux/synth.c:182-195) for n frames; vec host float[n].  With a communicator: the OR over all
+ * ranks' voices (collective). */
 int smx_bank_run_square(smx_bank *b, float *vec, int n);
 
 /* Timing on the bank's own stream (HIP events; ms). */

@@ -833,6 +833,17 @@ extern "C" int smx_bank_run_square(smx_bank *b, float *vec, int n)
     if (rv) return rv;
     b->elapsed += (uint32_t)n;
     b->bus_cur = bi;
+    if (b->comm) {
+        // a sharded bank: the OR over all ranks' voices.  Every word is 0 or 0x80000000, so the unsigned maximum
+        // is the OR (RCCL has no bitwise reduction); issued at once, after whatever was queued before it
+        rv = bank_comm_flush(b);
+        if (rv) return rv;
+        SMX_HIP(hipEventRecord(b->ev_kernel[bi], b->stream));
+        SMX_HIP(hipStreamWaitEvent(b->comm_stream, b->ev_kernel[bi], 0));
+        SMX_NCCL(ncclAllReduce(b->d_bus[bi], b->d_bus[bi], (size_t)n, ncclUint32, ncclMax, b->comm, b->comm_stream));
+        SMX_HIP(hipEventRecord(b->ev_comm[bi], b->comm_stream));
+        SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
+    }
     SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
     SMX_HIP(hipStreamSynchronize(b->stream));
     // linux/synth.c:194: (1.0 / 2^32) * (float)accu, accu unsigned

@@ -131,15 +131,17 @@ ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, n
 {
     Comm *c = reinterpret_cast<Comm *>(comm);
     Shm *s = c->shm;
-    if (datatype != ncclInt32 || op != ncclSum) die("only int32 sums are used by the product");
+    const bool is_max = datatype == ncclUint32 && op == ncclMax;            // sum_tick_square's OR of sign-bit words
+    if (!(datatype == ncclInt32 && op == ncclSum) && !is_max) die("only int32 sums and uint32 maxima are used by the product");
     if (count == 0 || count > MAX_COUNT) die("count out of range");
     if (hipStreamSynchronize(stream) != hipSuccess) die("hipStreamSynchronize failed");
     if (hipMemcpy(s->buf[c->rank], sendbuff, count * 4, hipMemcpyDeviceToHost) != hipSuccess) die("D2H failed");
-    s->count[c->rank] = count;
+    const unsigned long long tagged = count | (is_max ? 1ull << 41 : 0ull);
+    s->count[c->rank] = tagged;
     const unsigned long long my_seq = s->seq[c->rank].fetch_add(1) + 1;
     barrier(c);
     for (int r = 0; r < c->nranks; r++) {
-        if (s->count[r] != count) {
+        if (s->count[r] != tagged) {
             fprintf(stderr, "fake_rccl: rank %d issued a collective of %zu elements, rank %d one of %llu (collective #%llu)\n",
                     c->rank, count, r, s->count[r], my_seq);
             die("ranks issue different collectives: the SPMD contract is broken");
@@ -149,7 +151,10 @@ ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, n
     int32_t *sum = static_cast<int32_t *>(malloc(count * 4));
     for (size_t i = 0; i < count; i++) {
         uint32_t acc = 0;
-        for (int r = 0; r < c->nranks; r++) acc += (uint32_t)s->buf[r][i];      // wrapping, like the bus
+        for (int r = 0; r < c->nranks; r++) {
+            const uint32_t x = (uint32_t)s->buf[r][i];
+            acc = is_max ? (x > acc ? x : acc) : acc + x;                        // the sum wraps, like the bus
+        }
         sum[i] = (int32_t)acc;
     }
     barrier(c);                                             // everybody has read every operand

@@ -145,6 +145,12 @@ def main():
         res["checks"] += 1
     bank.set_block_mode(0)
     bank.sync()
+    # (5) sum_tick_square (linux/synth.c:182-195): the OR over every rank's voices
+    for nf in (64, 5):
+        got = bank.run_square(nf)
+        want = np.array([orc.orc_sum_tick_square(all_inc, all_st, len(all_inc)) for _ in range(nf)], np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "square"
+        res["checks"] += 1
     # phases of the shard after everything
     _, st = bank.read()
     assert np.array_equal(st, all_st[rank * per:(rank + 1) * per])
