@@ -431,65 +431,66 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         atomicAdd(&H[((u3 & 15) << 4) | (a.w & 15)], 1u);
         mx = max(max(mx, a.x), max(max(a.y, a.z), a.w));
         if constexpr (EVENTS) {
-            // (1) Which voices wrap in this chunk at all?  u + 64*inc >= 2^32.  In a piano-range bank
-            //     more than half do not, and they need neither the divisions nor the loop: the wave
-            //     compacts the (u, inc) pairs of its wrapping voices into its own LDS list ...
+            // (1) Which voices wrap in this chunk at all, and how often?  K = (u + 64*inc) >> 32.  In a
+            //     piano-range bank more than half do not wrap, and they need neither the divisions nor the
+            //     loop: the wave compacts the (u, inc) pairs of its wrapping voices into its own LDS list, the
+            //     busy ones (K >= 3) first, then the others ...
             const uint32_t vi[4] = {a.x, a.y, a.z, a.w}, vu[4] = {u0, u1, u2, u3};
             uint2 *list = &EL[(tid >> 6) * 256];
-            uint32_t nw = 0;                                  // wave-uniform
+            bool heavy[4], light[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const bool w = (vi[k] >> 26) != 0u || vu[k] + (vi[k] << 6) < vu[k];
-                const unsigned long long m = __ballot(w);
-                const uint32_t pos = nw + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (w) list[pos] = make_uint2(vu[k], vi[k]);
-                nw += (uint32_t)__builtin_popcountll(m);
+                const uint32_t lo = vu[k] + (vi[k] << 6);
+                const uint32_t K = (vi[k] >> 26) + (lo < vu[k] ? 1u : 0u);
+                heavy[k] = K >= 3u;
+                light[k] = K - 1u < 2u;
+            }
+            uint32_t nw = 0;                                  // wave-uniform
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool w = pass == 0 ? heavy[k] : light[k];
+                    const unsigned long long m = __ballot(w);
+                    const uint32_t pos = nw + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (w) list[pos] = make_uint2(vu[k], vi[k]);
+                    nw += (uint32_t)__builtin_popcountll(m);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // (2) ... and every lane takes entries lane, lane + 64, ...: the same number of wrapping
-            //     voices per lane (+-1) whatever their place in the bank.
-            uint32_t ei[4], et[4], er[4], eq[4], erm[4], ee[4];
-            bool more = false;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                et[k] = 0xFFFFFFFFu; ei[k] = er[k] = eq[k] = erm[k] = ee[k] = 0;
-                if (64u * k < nw) {                           // wave-uniform: empty slots cost nothing
-                    const uint32_t e = lane + 64u * k;
-                    const uint2 en = list[e < nw ? e : 0u];
-                    const uint32_t d = en.y;                  // > 0: an off voice never wraps
-                    const float rd = rcp_biased(d);
-                    // the voice wraps within the chunk, so ~u < 64 d: the first quotient is below 64
-                    const uint32_t n1 = div_small(~en.x, d, rd);
-                    // Q < 64 exactly when d >= 2^26; a smaller increment wraps at most once per chunk and any
-                    // gap beyond the chunk is as good as any other (2^30 keeps et + gap from wrapping)
-                    eq[k] = (d >> 26) ? div_small(0xFFFFFFFFu, d, rd) : (1u << 30);
-                    erm[k] = 0xFFFFFFFFu - eq[k] * d;         // (meaningless, and unused, in the second case)
-                    ee[k] = d - 1u - erm[k];
-                    er[k] = en.x + (n1 + 1u) * d;             // mod 2^32: the phase right after the first wrap
-                    ei[k] = d;
-                    if (e < nw) et[k] = n1;
-                    more |= et[k] < 64u;
+            // (2) ... and the lanes take entries lane, lane + 64, ... slot by slot: the same number of wrapping
+            //     voices per lane (+-1) whatever their place in the bank, and because the busy voices sit together
+            //     in the first slot(s), a slot's loop runs as long as ITS busiest voice, not the wave's (a
+            //     piano-range row: ~5.5 rounds over the first slot and 2 over the second, instead of 6 over both)
+            for (uint32_t k = 0; 64u * k < nw; k++) {            // wave-uniform trip count
+                const uint32_t e = lane + 64u * k;
+                const uint2 en = list[e < nw ? e : 0u];
+                const uint32_t d = en.y;                          // > 0: an off voice never wraps
+                const float rd = rcp_biased(d);
+                // the voice wraps within the chunk, so ~u < 64 d: the first quotient is below 64
+                const uint32_t n1 = div_small(~en.x, d, rd);
+                // Q < 64 exactly when d >= 2^26; a smaller increment wraps at most once per chunk and any
+                // gap beyond the chunk is as good as any other (2^30 keeps et + gap from wrapping)
+                const uint32_t eq = (d >> 26) ? div_small(0xFFFFFFFFu, d, rd) : (1u << 30);
+                const uint32_t erm = 0xFFFFFFFFu - eq * d;        // (meaningless, and unused, in the second case)
+                const uint32_t ee = d - 1u - erm;
+                uint32_t er = en.x + (n1 + 1u) * d;               // mod 2^32: the phase right after the first wrap
+                uint32_t et = e < nw ? n1 : 0xFFFFFFFFu;
+                // every gap is at least one frame, so 64 rounds always suffice: the bound makes the
+                // loop finite whatever the data
+                for (int round = 0; round < 64 && __any(et < 64u); round++) {
+                    if (et < 64u) {
+                        atomicAdd(&M[et][lane], 1u);             // own column: no lane ever shares an address
+                        const bool c = er <= erm;
+                        et += eq + (c ? 1u : 0u);
+                        er += c ? ee : ee - d;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // list is free for the next row
             __builtin_amdgcn_wave_barrier();
-            // every gap is at least one frame, so 64 rounds always suffice: the bound makes the
-            // loop finite whatever the data
-            for (int round = 0; round < 64 && __any(more); round++) {
-                more = false;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (et[k] < 64u) {
-                        atomicAdd(&M[et[k]][lane], 1u);     // own column: no lane ever shares an address
-                        const bool c = er[k] <= erm[k];
-                        et[k] += eq[k] + (c ? 1u : 0u);
-                        er[k] += c ? ee[k] : ee[k] - ei[k];
-                        more |= et[k] < 64u;
-                    }
-                }
-            }
         } else {
 #pragma unroll
             for (int t = 0; t < TC; t++) {
