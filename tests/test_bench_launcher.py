@@ -94,3 +94,24 @@ def test_bench_does_not_import_torch():
     assert "import torch" not in src
     rdzv = open(os.path.join(ROOT, "synth_tools_amd", "rendezvous.py")).read()
     assert "import torch" not in rdzv
+
+
+def test_the_rccl_test_double_builds():
+    """tests/c/fake_rccl.cpp (used by the GPU multi-rank tests) compiles and exports exactly the RCCL entry
+    points the product calls -- checked against the product's own undefined nccl* symbols."""
+    import shutil
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc) or not shutil.which("nm"):
+        import pytest
+        pytest.skip("no hipcc / nm here")
+    out = os.path.join(tempfile.mkdtemp(prefix="smx_fake_"), "fake_rccl.so")
+    p = subprocess.run([hipcc, "-O2", "-shared", "-fPIC", "-o", out, os.path.join(ROOT, "tests", "c", "fake_rccl.cpp"), "-lrt"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    have = {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", out], capture_output=True, text=True).stdout.splitlines()
+            if " T nccl" in l}
+    lib = os.path.join(ROOT, "synth_tools_amd", "libsynth_mi355x.so")
+    need = {l.split()[-1].split("@")[0] for l in subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout.splitlines()
+            if " U nccl" in l}
+    assert need and need <= have, (sorted(need - have), sorted(have))
