@@ -142,7 +142,10 @@ int smx_bank_set_block_form(smx_bank *b, int form);
 int smx_bank_next_block_form(smx_bank *b);
 
 /* Asynchronous form: enqueue one block of n frames on the bank's stream and
- * leave the int32 bus in device memory (smx_bank_bus_dev).  No host sync. */
+ * leave the int32 bus in device memory (smx_bank_bus_dev).  No host sync.
+ * (Some block shapes leave the last fold of their partial sums to the next block's launch; smx_bank_bus_dev,
+ * _fetch, _sync and the all-reduce calls enqueue it when it is still owed, so the bus they hand out is complete.
+ * Take the device pointer AFTER the run_async call it belongs to, through smx_bank_bus_dev.) */
 int   smx_bank_run_async(smx_bank *b, int n);
 void *smx_bank_bus_dev(smx_bank *b);     /* device int32[n] of the last block */
 int   smx_bank_sync(smx_bank *b);

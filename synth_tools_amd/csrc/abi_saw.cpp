@@ -143,6 +143,7 @@ struct smx_bank {
     int pipe_n[2] = {0, 0};                      // frames held by each slot (0: nothing yet)
     uint32_t pipe_k = 0;
     void *d_scratch = nullptr;                   // partial sums of saw_bank.hip's carry formulation
+    smx::SawPending pend;                        // the slot fold the last launch left to its successor (smx_common.h)
     hipStream_t stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     hipEvent_t ev_kernel[NBUS] = {};             // kernel of bus[i] finished
@@ -196,9 +197,17 @@ static inline bool bank_owns(const smx_bank *b, uint32_t v, uint32_t *local)
     return true;
 }
 
+// Whoever is about to read the current bus buffer (or to write the next one outside a saw launch) first runs the
+// fold the last slot launch deferred; a no-op when nothing is owed.
+static int bank_flush_fold(smx_bank *b) { return smx::launch_saw_flush(&b->pend, b->stream); }
+
 static int bank_ensure_bus(smx_bank *b, uint32_t n)
 {
     if (n <= b->bus_cap) return SMX_OK;
+    {
+        int rv = bank_flush_fold(b);                 // it refers to the buffers being replaced
+        if (rv) return rv;
+    }
     if (b->comm) {                                   // queued sums refer to the buffers being replaced
         int rv = bank_comm_flush(b);
         if (rv) return rv;
@@ -209,7 +218,9 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
     if (b->d_ring) SMX_HIP(hipFree(b->d_ring));
     b->d_ring = nullptr;
     SMX_HIP(hipMalloc((void **)&b->d_ring, (size_t)smx_bank::NBUS * cap * 4));
-    SMX_HIP(hipMemset(b->d_ring, 0, (size_t)smx_bank::NBUS * cap * 4));
+    // (stream-ordered: hipMemset on the null stream is asynchronous to the host and b->stream, a non-blocking
+    // stream, would not wait for it -- the first block's kernel could meet a buffer that is cleared under it)
+    SMX_HIP(hipMemsetAsync(b->d_ring, 0, (size_t)smx_bank::NBUS * cap * 4, b->stream));
     for (int i = 0; i < smx_bank::NBUS; i++) {
         b->d_bus[i] = b->d_ring + (size_t)i * cap;
         b->bus_zeroed[i] = cap;
@@ -225,8 +236,11 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
         if (b->d_scratch) SMX_HIP(hipFree(b->d_scratch));
         b->d_scratch = nullptr;
         SMX_HIP(hipMalloc(&b->d_scratch, smx::saw_scratch_bytes(scap)));
-        SMX_HIP(hipMemset(b->d_scratch, 0, smx::saw_scratch_bytes(scap)));   // slots are kept zero between launches
+        SMX_HIP(hipMemsetAsync(b->d_scratch, 0, smx::saw_scratch_bytes(scap), b->stream));   // slots are kept zero between launches
         b->scratch_cap = scap;
+        static const bool no_defer = getenv("SMX_SAW_NO_DEFER") != nullptr;      // A/B switch: every launch folds its own slots
+        b->pend = smx::SawPending{};
+        b->pend.region_stride = no_defer ? 0 : smx::saw_scratch_region_bytes(scap);
         // a new header: the form pick starts at "stepping", the sum of the increments is computed again
         int rv = smx::launch_saw_sum_inc(b->d_inc, b->n_pad, b->d_scratch, b->stream);
         if (rv) return rv;
@@ -494,6 +508,10 @@ extern "C" int smx_bank_note_off(smx_bank *b, int note)
 static int bank_comm_flush(smx_bank *b)
 {
     if (b->ar_count == 0) return SMX_OK;
+    {
+        int rv = bank_flush_fold(b);                 // the youngest queued block may still owe its fold
+        if (rv) return rv;
+    }
     const int first = b->ar_queue[0], last = b->ar_queue[b->ar_count - 1];
     SMX_HIP(hipEventRecord(b->ev_kernel[last], b->stream));
     SMX_HIP(hipStreamWaitEvent(b->comm_stream, b->ev_kernel[last], 0));
@@ -592,7 +610,7 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
             form = b->form_seen ? SMX_FORM_EVENTS : SMX_FORM_STEPPING;
     }
     rv = smx::launch_saw_bank(b->d_inc, b->d_state0, b->d_bus[bi], b->d_bus[bnext], b->n_pad, (uint32_t)n,
-                              b->elapsed, b->d_scratch, form, b->h_form, b->stream);
+                              b->elapsed, b->d_scratch, form, b->h_form, b->stream, &b->pend);
     if (rv) return rv;
     b->elapsed += (uint32_t)n;             // mod 2^32, like the phases
     b->bus_zeroed[bi] = 0;                 // now holds this block's sums
@@ -601,7 +619,11 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
     return SMX_OK;
 }
 
-extern "C" void *smx_bank_bus_dev(smx_bank *b) { return b ? b->d_bus[b->bus_cur] : nullptr; }
+extern "C" void *smx_bank_bus_dev(smx_bank *b)
+{
+    if (!b || hipSetDevice(b->device) != hipSuccess || bank_flush_fold(b) != SMX_OK) return nullptr;
+    return b->d_bus[b->bus_cur];
+}
 
 // process_midi dispatch (linux/synth.c:236-258) for one event, on the bank
 extern "C" int smx_bank_midi_event(smx_bank *b, const uint8_t *msg, size_t size)
@@ -685,8 +707,10 @@ extern "C" int smx_bank_sync(smx_bank *b)
 {
     if (!b) return SMX_E_ARG;
     SMX_HIP(hipSetDevice(b->device));
+    int rv = bank_flush_fold(b);                 // after a sync the current bus buffer holds its sums
+    if (rv) return rv;
     if (b->comm) {
-        int rv = bank_comm_flush(b);
+        rv = bank_comm_flush(b);
         if (rv) return rv;
     }
     SMX_HIP(hipStreamSynchronize(b->stream));
@@ -699,8 +723,10 @@ extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
     if (!b || n <= 0 || (uint32_t)n > b->bus_cap) { set_error("smx_bank_fetch: bad args"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
     const int bi = b->bus_cur;
+    int rv = bank_flush_fold(b);
+    if (rv) return rv;
     if (bank_ar_queued(b, bi)) {                   // somebody needs the sum now: issue the group
-        int rv = bank_comm_flush(b);
+        rv = bank_comm_flush(b);
         if (rv) return rv;
     }
     if (b->comm_pending[bi]) {
@@ -770,6 +796,8 @@ static int bank_run_pipelined(smx_bank *b, float *vec, int32_t *bus, int n)
     }
     int rv = smx_bank_run_async(b, n);
     if (rv) return rv;
+    rv = bank_flush_fold(b);                     // the copy below reads this block's bus
+    if (rv) return rv;
     const int cur = b->pipe_k & 1, prev = cur ^ 1;
     const int bi = b->bus_cur;
     if (b->comm) {
@@ -822,6 +850,8 @@ extern "C" int smx_bank_run_square(smx_bank *b, float *vec, int n)
     if (!b || n <= 0) { set_error("smx_bank_run_square: bad args"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
     int rv = bank_ensure_bus(b, (uint32_t)n);
+    if (rv) return rv;
+    rv = bank_flush_fold(b);                     // an owed fold would zero the buffer this block writes
     if (rv) return rv;
     const int bi = (b->bus_cur + 1) % smx_bank::NBUS;
     rv = bank_bus_release(b, bi);

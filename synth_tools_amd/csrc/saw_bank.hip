@@ -114,6 +114,36 @@ struct SawPartial {
 constexpr uint32_t SAW_EVENTS_MAX_INC = 13u << 25;          // 6.5 wraps per 64 frames (MIDI note 110 at 48 kHz)
 constexpr size_t SAW_SCRATCH_HEADER = 64;
 
+// Fold of one 64-frame row of slots (256 threads): sum the SAW_SLOTS copies, clear them for the next launch,
+// write the bus and keep the "next bus buffer is zero" contract.
+__device__ __forceinline__
+void saw_direct_fold(SawPartial *__restrict__ partial, int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
+                     uint32_t nframes, uint32_t row, uint32_t (*Ws)[64])
+{
+    const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
+    SawPartial *p = partial + (size_t)row * SAW_SLOTS;
+    uint32_t wv[SAW_SLOTS / 4];
+#pragma unroll
+    for (int k = 0; k < SAW_SLOTS / 4; k++) wv[k] = p[part + 4 * k].W[t];
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < SAW_SLOTS / 4; k++) { w += wv[k]; p[part + 4 * k].W[t] = 0; }
+    Ws[part][t] = w;
+    __syncthreads();
+    const uint32_t f = row * 64u + t;
+    if (part == 0 && f < nframes) {
+        bus[f] = (int32_t)(Ws[0][t] + Ws[1][t] + Ws[2][t] + Ws[3][t]);
+        bus_next[f] = 0;
+    }
+}
+
+// The fold a slot launch still owes for its PREDECESSOR (smx::SawPending): rows of `partial`, nullptr for none.
+struct SawOwed {
+    SawPartial *partial;
+    int32_t *bus, *bus_next;
+    uint32_t nframes;
+};
+
 // SLOT: instead of one atomic per frame per workgroup on the bus itself (same-address integer
 // atomics serialise at ~20 ns: 2048 workgroups ending together cost 40 us), the workgroup adds
 // its frame sums into one of SAW_SLOTS copies (SawPartial::W) and saw_direct_finalize_kernel
@@ -127,7 +157,8 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
                      uint32_t ngroups,      // n_pad / VW
                      uint32_t nframes,      // total frames of this block
                      uint32_t tbase,        // frames elapsed since state0 was valid
-                     SawPartial *__restrict__ partial)   // SLOT only: zeroed slots, SAW_SLOTS per chunk
+                     SawPartial *__restrict__ partial,   // SLOT only: zeroed slots, SAW_SLOTS per chunk
+                     SawOwed owed)                       // SLOT only: the previous block's slots, folded here
 {
     __shared__ int32_t M[TC][65];
     const uint32_t tid = threadIdx.x;
@@ -168,6 +199,15 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
                 qa[k] = stream_load<NT>(reinterpret_cast<const u32x4 *>(inc) + r);
                 qb[k] = stream_load<NT>(reinterpret_cast<const u32x4 *>(st_in) + r);
             }
+        }
+    }
+    if constexpr (SLOT) {
+        // the previous slot launch left its fold to this one (other slot region, so no clash with this launch's
+        // atomics): the first workgroups take one 64-frame row each while their own first rows are in flight
+        const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (owed.partial && wg < (owed.nframes + 63u) / 64u) {
+            __shared__ uint32_t Ws[4][64];
+            saw_direct_fold(owed.partial, owed.bus, owed.bus_next, owed.nframes, wg, Ws);
         }
     }
     const uint32_t g_first = (VW == 4) ? blockIdx.x : blockIdx.x * 256u + tid;
@@ -236,21 +276,7 @@ void saw_direct_finalize_kernel(SawPartial *__restrict__ partial, int32_t *__res
                                 int32_t *__restrict__ bus_next, uint32_t nframes)
 {
     __shared__ uint32_t Ws[4][64];
-    const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
-    SawPartial *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
-    uint32_t wv[SAW_SLOTS / 4];
-#pragma unroll
-    for (int k = 0; k < SAW_SLOTS / 4; k++) wv[k] = p[part + 4 * k].W[t];
-    uint32_t w = 0;
-#pragma unroll
-    for (int k = 0; k < SAW_SLOTS / 4; k++) { w += wv[k]; p[part + 4 * k].W[t] = 0; }
-    Ws[part][t] = w;
-    __syncthreads();
-    const uint32_t f = blockIdx.x * 64u + t;
-    if (part == 0 && f < nframes) {
-        bus[f] = (int32_t)(Ws[0][t] + Ws[1][t] + Ws[2][t] + Ws[3][t]);
-        bus_next[f] = 0;
-    }
+    saw_direct_fold(partial, bus, bus_next, nframes, blockIdx.x, Ws);
 }
 
 // Few-frame blocks (the tick ABI: 1..4 frames) of banks with >= 2^20 voices: the same direct
@@ -980,9 +1006,21 @@ static uint32_t grid_size(uint32_t tc, uint32_t rows, uint32_t gy)
     return gx < 1 ? 1 : gx;
 }
 
+// Run the fold a slot launch left behind (smx::SawPending) as a kernel of its own.
+int flush_pending(smx::SawPending *pend, hipStream_t stream)
+{
+    if (!pend || !pend->partial) return SMX_OK;
+    hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3((pend->nframes + 63) / 64), dim3(256), 0, stream,
+                       static_cast<SawPartial *>(pend->partial), pend->bus, pend->bus_next, pend->nframes);
+    pend->partial = nullptr;
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
 template <int TC, int VW, bool NT>
 int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bus_next,
-              uint32_t n_pad, uint32_t nframes, uint32_t tbase, SawPartial *partial, hipStream_t stream)
+              uint32_t n_pad, uint32_t nframes, uint32_t tbase, SawPartial *partial, hipStream_t stream,
+              smx::SawPending *pend)
 {
     const uint32_t ngroups = n_pad / VW;
     const uint32_t gy = (nframes + TC - 1) / TC;                 // chunks of TC frames
@@ -998,17 +1036,41 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
             // 64 Mi voices x 5 frames 79 us = 6.8 TB/s vs 90 us with 2048)
             uint32_t gx = ((env ? (uint32_t)atoi(env) : (TC <= 8 ? 1024u : 2048u)) + gy - 1) / gy;
             if (gx > rows) gx = rows;
+            SawOwed owed{nullptr, nullptr, nullptr, 0};
+            if (pend && pend->region_stride) {
+                // deferred fold: this launch folds its predecessor's slots and fills the other region
+                if (pend->partial && (pend->nframes + 63) / 64 > gx * gy) {
+                    const int rv = flush_pending(pend, stream);
+                    if (rv) return rv;
+                }
+                if (pend->partial)
+                    owed = SawOwed{static_cast<SawPartial *>(pend->partial), pend->bus, pend->bus_next, pend->nframes};
+                partial = reinterpret_cast<SawPartial *>(reinterpret_cast<char *>(partial) + pend->region * pend->region_stride);
+            }
             hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT, true>), dim3(gx, gy), dim3(256), 0, stream,
-                               inc, si, bus, bus_next, ngroups, nframes, tbase, partial);
-            hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3(gy64), dim3(256), 0, stream, partial, bus,
-                               bus_next, nframes);
+                               inc, si, bus, bus_next, ngroups, nframes, tbase, partial, owed);
+            if (pend && pend->region_stride) {
+                pend->partial = partial;
+                pend->bus = bus;
+                pend->bus_next = bus_next;
+                pend->nframes = nframes;
+                pend->region ^= 1u;
+            } else {
+                hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3(gy64), dim3(256), 0, stream, partial, bus,
+                                   bus_next, nframes);
+            }
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         }
     }
+    {
+        const int rv = flush_pending(pend, stream);     // this launch adds to the bus the owed fold still has to zero
+        if (rv) return rv;
+    }
     const uint32_t gx = grid_size(TC, rows, gy);
     hipLaunchKernelGGL((saw_bank_kernel<TC, VW, NT, false>), dim3(gx, gy), dim3(256), 0, stream,
-                       inc, si, bus, bus_next, ngroups, nframes, tbase, (SawPartial *)nullptr);
+                       inc, si, bus, bus_next, ngroups, nframes, tbase, (SawPartial *)nullptr,
+                       SawOwed{nullptr, nullptr, nullptr, 0});
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
@@ -1017,16 +1079,17 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
 // blockIdx.y.  64 for big banks; small banks take shorter chunks (launch_saw_bank).
 template <int VW, bool NT>
 int launch_vw(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bus_next,
-              uint32_t n_pad, uint32_t nframes, uint32_t tbase, SawPartial *partial, uint32_t tc_cap, hipStream_t stream)
+              uint32_t n_pad, uint32_t nframes, uint32_t tbase, SawPartial *partial, uint32_t tc_cap, hipStream_t stream,
+              smx::SawPending *pend)
 {
     const uint32_t nf = nframes < tc_cap ? nframes : tc_cap;
-    if (nf > 32) return launch_tc<64, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nf > 16) return launch_tc<32, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nf > 8)  return launch_tc<16, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nf > 4)  return launch_tc<8, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nf > 2)  return launch_tc<4, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    if (nf > 1)  return launch_tc<2, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
-    return launch_tc<1, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream);
+    if (nf > 32) return launch_tc<64, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream, pend);
+    if (nf > 16) return launch_tc<32, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream, pend);
+    if (nf > 8)  return launch_tc<16, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream, pend);
+    if (nf > 4)  return launch_tc<8, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream, pend);
+    if (nf > 2)  return launch_tc<4, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream, pend);
+    if (nf > 1)  return launch_tc<2, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream, pend);
+    return launch_tc<1, VW, NT>(inc, si, bus, bus_next, n_pad, nframes, tbase, partial, stream, pend);
 }
 
 }  // namespace
@@ -1035,14 +1098,21 @@ namespace smx {
 
 size_t saw_scratch_header_bytes() { return SAW_SCRATCH_HEADER; }
 
-size_t saw_scratch_bytes(uint32_t max_frames)
+size_t saw_scratch_region_bytes(uint32_t max_frames)
 {
-    return SAW_SCRATCH_HEADER + (size_t)SAW_SLOTS * ((max_frames + 63) / 64 + 1) * sizeof(SawPartial);
+    return (size_t)SAW_SLOTS * ((max_frames + 63) / 64 + 1) * sizeof(SawPartial);
 }
+
+// header + two slot regions (the second one only for the deferred fold of the direct form's slot launches;
+// the carry formulations use the area from the first region on, with nothing owed)
+size_t saw_scratch_bytes(uint32_t max_frames) { return SAW_SCRATCH_HEADER + 2 * saw_scratch_region_bytes(max_frames); }
+
+int launch_saw_flush(SawPending *pend, hipStream_t stream) { return flush_pending(pend, stream); }
 
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
-                    void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream)
+                    void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream,
+                    SawPending *pend)
 {
     if (n_pad == 0 || (n_pad & 1023) || nframes == 0) {
         set_error("launch_saw_bank: n_pad=%u nframes=%u", n_pad, nframes);
@@ -1073,7 +1143,11 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
         // the packed 16-bit scalar counters take 128 carries per trip: stay below 400 trips
         // (banks that would need more workgroups than the scratch holds use the direct form)
         const uint32_t trips = (ngroups + gx * 256u - 1) / (gx * 256u);
-        if (trips <= 400 && (size_t)SAW_SLOTS * gy * sizeof(SawPartial) <= saw_scratch_bytes(nframes)) {
+        if (trips <= 400 && (size_t)SAW_SLOTS * gy * sizeof(SawPartial) <= saw_scratch_region_bytes(nframes)) {
+            {
+                const int rv = flush_pending(pend, stream);       // the slots must be all zero, the bus cleared
+                if (rv) return rv;
+            }
             auto *flag = static_cast<uint32_t *>(d_scratch);
             auto *part = reinterpret_cast<SawPartial *>(static_cast<char *>(d_scratch) + SAW_SCRATCH_HEADER);   // all zero between launches
             const bool no_events = long_block_form == SMX_FORM_STEPPING;
@@ -1143,6 +1217,10 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
         if (gx > cap) gx = cap;
         if (gx < 1) gx = 1;
         const bool nt = n_pad >= (1u << 24);
+        {
+            const int rv = flush_pending(pend, stream);
+            if (rv) return rv;
+        }
 #define SMX_TICK_LAUNCH(TC_, NT_)                                                              \
     hipLaunchKernelGGL((saw_tick_kernel<TC_, NT_>), dim3(gx), dim3(1024), 0, stream, d_inc,    \
                        d_state_in, d_bus, d_bus_next, ngroups, nframes, tbase)
@@ -1158,16 +1236,16 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     // Infinity Cache between launches anyway
     // slots need one SawPartial row per 64-frame chunk in the scratch
     SawPartial *part = nullptr;
-    if (d_scratch && (size_t)SAW_SLOTS * ((nframes + 63) / 64) * sizeof(SawPartial) <= saw_scratch_bytes(nframes))
+    if (d_scratch && (size_t)SAW_SLOTS * ((nframes + 63) / 64) * sizeof(SawPartial) <= saw_scratch_region_bytes(nframes))
         part = reinterpret_cast<SawPartial *>(static_cast<char *>(d_scratch) + SAW_SCRATCH_HEADER);
     static const char *tcc = getenv("SMX_SAW_TC_CAP");                  // tuning overrides
     static const char *svw = getenv("SMX_SAW_SMALL_VW");
     static const char *stc = getenv("SMX_SAW_SMALL_TC");
     const uint32_t tc_cap = tcc ? (uint32_t)atoi(tcc) : 64u;
     if (n_pad >= (1u << 24))
-        return launch_vw<4, true>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, tc_cap, stream);
+        return launch_vw<4, true>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, tc_cap, stream, pend);
     if (n_pad >= (1u << 20))
-        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, tc_cap, stream);
+        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, tc_cap, stream, pend);
     // Small banks (< 2^20 voices): 4 voices per lane as well (16-byte loads) and chunks of 16 frames on
     // blockIdx.y, so that a 64-frame block of 65 536 voices is 64 x 4 workgroups with 64 bus atomics per
     // frame instead of 128 x 1 with 128: the launch is bound by the same-address atomics at its end
@@ -1175,8 +1253,8 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     const uint32_t small_tc = stc ? (uint32_t)atoi(stc) : 16u;
     const bool small_vw4 = svw ? atoi(svw) == 4 : n_pad >= (1u << 13);
     if (small_vw4)
-        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, nullptr, small_tc, stream);
-    return launch_vw<1, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, nullptr, small_tc, stream);
+        return launch_vw<4, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, nullptr, small_tc, stream, pend);
+    return launch_vw<1, false>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, nullptr, small_tc, stream, pend);
 }
 
 int launch_square_bank(const uint32_t *d_inc, const uint32_t *d_state_in, uint32_t *d_or_bus,

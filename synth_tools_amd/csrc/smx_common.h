@@ -44,12 +44,28 @@ static inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m
 // (partial-sum slots of the carry formulation; each launch leaves them zero again), or NULL
 // to force the direct formulation.
 size_t saw_scratch_bytes(uint32_t max_frames);
+// The slot variants of the direct formulation (>= 2^20 voices, 5+ frames, below the carry crossover) end in a
+// small fold of their slots into the bus.  With a SawPending that fold is DEFERRED: the next slot launch does it
+// in its first workgroups (the scratch holds two slot regions, used alternately), anything else that needs the
+// bus -- a fetch, an all-reduce, a launch of another form -- calls launch_saw_flush first.  The stream then
+// carries one kernel per block instead of two.  Until the fold has run, `bus` holds no valid sums and
+// `bus_next` is not yet zeroed.
+struct SawPending {
+    void *partial = nullptr;            // slots of the block whose fold is owed (nullptr: nothing owed)
+    int32_t *bus = nullptr, *bus_next = nullptr;
+    uint32_t nframes = 0;
+    uint32_t region = 0;                // slot region the NEXT slot launch fills
+    size_t region_stride = 0;           // bytes between the two regions: saw_scratch_region_bytes(cap the scratch has)
+};
+size_t saw_scratch_region_bytes(uint32_t max_frames);
+int launch_saw_flush(SawPending *pend, hipStream_t stream);
 // long_block_form: SMX_FORM_AUTO / SMX_FORM_STEPPING / SMX_FORM_EVENTS (include/synth_mi355x.h)
 // host_flag: two pinned (device-visible) words that receive, after every long block, the form the device
 // would pick next (0 stepping, 1 events) and the number of long blocks finalized so far; or NULL.
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state0, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
-                    void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream);
+                    void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream,
+                    SawPending *pend = nullptr);      // pend == nullptr: every launch folds its own slots
 // leading bytes of the scratch area that hold the formulation flag (zero: stepping form) and the bank's sum of
 // increments; after clearing them (new increments) launch_saw_sum_inc recomputes the sum
 size_t saw_scratch_header_bytes();

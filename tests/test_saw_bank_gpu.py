@@ -565,3 +565,57 @@ def test_auto_form_statistic_is_conservative_under_note_events(smx, orc, inc_tab
     _, gst = bank.read()
     assert np.array_equal(gst, st)
     bank.close()
+
+
+def test_deferred_slot_fold_sequences(smx, orc, inc_table):
+    """Blocks of 5+ frames on >= 2^20 voices below the carry crossover leave the fold of their slots to the NEXT
+    launch (smx_common.h SawPending) or to whoever reads the bus.  Un-fetched blocks in a row, every kind of
+    successor (slot launch with another chunk length, tick kernel, carry forms, square variant, a longer block that
+    replaces the ring), events and reloads in between: each fetched bus must equal the oracle's."""
+    rng = np.random.default_rng(0xF01D)
+    n = (1 << 20) + 5
+    inc, state = synthetic.saw_bank(n, 0x5EED0F01, inc_table, active_fraction=0.8)
+    bank = smx.SawBank(n)
+    bank.load(inc, state)
+    st = state.copy()
+    frames = [5, 8, 9, 16, 17, 32, 33, 64, 65, 100, 128, 200, 1, 3, 4]
+    n2v = np.zeros(128, np.int32)
+    inc = inc.copy()
+    checked = 0
+    for step in range(120):
+        nf = int(rng.choice(frames)) if step != 60 else 5000          # 5000: the ring and the scratch are replaced
+        r = rng.random()
+        if r < 0.08:
+            got = bank.run_square(nf)
+            want = np.array([orc.orc_sum_tick_square(inc, st, n) for _ in range(nf)], np.float32)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), ("square", step, nf)
+            checked += 1
+            continue
+        if r < 0.16:
+            note = int(rng.integers(0, 128))
+            bank.note_on(note)
+            orc.orc_note_on(n2v, inc, n, note)
+        bank.run_async(nf)
+        want, wvec = oracle.synth_run(orc, inc, st, nf)
+        if rng.random() < 0.4 or step in (59, 60, 61, 119):
+            bus, vec = bank.fetch(nf)
+            assert np.array_equal(bus, want), ("bus", step, nf)
+            assert np.array_equal(vec.view(np.uint32), wvec.view(np.uint32))
+            checked += 1
+    assert checked >= 40
+    ginc, gst = bank.read()
+    assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+    bank.close()
+    # the same through a communicator (1 rank): groups of 8 un-fetched blocks per all-reduce
+    bank = smx.SawBank(n)
+    bank.load(inc, state)
+    bank.comm_init(0, 1, smx.comm_unique_id())
+    st = state.copy()
+    for step in range(40):
+        nf = int(rng.choice([8, 16, 64, 3, 100]))
+        bank.run_async(nf)
+        bank.allreduce_async(nf)
+        want, _ = oracle.synth_run(orc, inc, st, nf)
+        if step % 7 == 6 or step == 39:
+            assert np.array_equal(bank.fetch(nf)[0], want), ("comm", step, nf)
+    bank.close()
