@@ -572,7 +572,8 @@ def test_deferred_slot_fold_sequences(smx, orc, inc_table):
     launch (smx_common.h SawPending) or to whoever reads the bus.  Un-fetched blocks in a row, every kind of
     successor (slot launch with another chunk length, tick kernel, carry forms, square variant, a longer block that
     replaces the ring), events and reloads in between: each fetched bus must equal the oracle's."""
-    rng = np.random.default_rng(0xF01D)
+    rng = np.random.default_rng(0xF01D ^ int(os.environ.get("SMX_FUZZ_SEED", "0"), 0))
+    rounds = int(os.environ.get("SMX_FUZZ_ROUNDS", "1"))
     n = (1 << 20) + 5
     inc, state = synthetic.saw_bank(n, 0x5EED0F01, inc_table, active_fraction=0.8)
     bank = smx.SawBank(n)
@@ -582,7 +583,7 @@ def test_deferred_slot_fold_sequences(smx, orc, inc_table):
     n2v = np.zeros(128, np.int32)
     inc = inc.copy()
     checked = 0
-    for step in range(120):
+    for step in range(120 * rounds):
         nf = int(rng.choice(frames)) if step != 60 else 5000          # 5000: the ring and the scratch are replaced
         r = rng.random()
         if r < 0.08:
@@ -597,7 +598,7 @@ def test_deferred_slot_fold_sequences(smx, orc, inc_table):
             orc.orc_note_on(n2v, inc, n, note)
         bank.run_async(nf)
         want, wvec = oracle.synth_run(orc, inc, st, nf)
-        if rng.random() < 0.4 or step in (59, 60, 61, 119):
+        if rng.random() < 0.4 or step in (59, 60, 61, 120 * rounds - 1):
             bus, vec = bank.fetch(nf)
             assert np.array_equal(bus, want), ("bus", step, nf)
             assert np.array_equal(vec.view(np.uint32), wvec.view(np.uint32))
