@@ -62,6 +62,37 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, uint32_t iters, uint32_
                                : "+v"(a), "+v"(x), "=&v"(m64) : "v"(ldsaddr) : "vcc", "memory");)
         } else if constexpr (V == 15) { // v_mov_b64 only
             REP64(asm volatile("v_mov_b64 %0, vcc" : "=v"(m64));)
+        } else if constexpr (V == 16) { // software-pipelined: add_co e64 (tick t) + one-lane-EXEC v_mov_b64 of tick t-1's mask
+            asm volatile("s_mov_b64 s[68:69], 1" ::: "s68", "s69");
+            REP8(REP8(asm volatile(
+                "v_add_co_u32_e64 %0, s[64:65], %0, %2\n\t"
+                "s_mov_b64 exec, s[68:69]\n\t"
+                "v_mov_b64 %1, s[66:67]\n\t"
+                "s_lshl_b64 s[68:69], s[68:69], 1\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "v_add_co_u32_e64 %0, s[66:67], %0, %2\n\t"
+                "s_mov_b64 exec, s[68:69]\n\t"
+                "v_mov_b64 %1, s[64:65]\n\t"
+                "s_lshl_b64 s[68:69], s[68:69], 1\n\t"
+                "s_mov_b64 exec, -1"
+                : "+v"(a), "+v"(m64) : "v"(x) : "s64", "s65", "s66", "s67", "s68", "s69", "scc");))   // 2 ticks per block
+        } else if constexpr (V == 17) { // the same with the EXEC switches left out (full-EXEC v_mov_b64; timing only)
+            REP8(REP8(asm volatile(
+                "v_add_co_u32_e64 %0, s[64:65], %0, %2\n\t"
+                "v_mov_b64 %1, s[66:67]\n\t"
+                "v_add_co_u32_e64 %0, s[66:67], %0, %2\n\t"
+                "v_mov_b64 %1, s[64:65]"
+                : "+v"(a), "+v"(m64) : "v"(x) : "s64", "s65", "s66", "s67");))
+        } else if constexpr (V == 18) { // pipelined, via VCC (e32 add) and a scalar copy: add_co e32, s_mov mask, one-lane v_mov_b64
+            asm volatile("s_mov_b64 s[68:69], 1" ::: "s68", "s69");
+            REP64(asm volatile(
+                "v_add_co_u32_e32 %0, vcc, %2, %0\n\t"
+                "s_mov_b64 exec, s[68:69]\n\t"
+                "v_mov_b64 %1, s[66:67]\n\t"
+                "s_lshl_b64 s[68:69], s[68:69], 1\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_mov_b64 s[66:67], vcc"
+                : "+v"(a), "+v"(m64) : "v"(x) : "vcc", "s66", "s67", "s68", "s69", "scc");)
         } else if constexpr (V == 12) { // plain VALU add for reference
             REP64(asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(x));)
         }
@@ -103,5 +134,8 @@ int main()
     run<15>("v_mov_b64 v[..], vcc", 1, out);
     run<13>("add_co(vcc) + s_nop 1 + v_mov_b64 + ds_write_b64 (lane 0 only, offset = tick)", 1, out);
     run<9>("stream step: add_co e64 + 2 v_add + addc e64", 1, out);
+    run<16>("pipelined: add_co e64 + one-lane-EXEC v_mov_b64 (2 s_mov exec + s_lshl per tick)", 2, out);
+    run<17>("the same without the EXEC switches (timing only)", 2, out);
+    run<18>("pipelined via vcc: add_co e32, one-lane v_mov_b64 of the previous mask, s_mov copy", 1, out);
     return 0;
 }
