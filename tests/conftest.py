@@ -31,3 +31,25 @@ def smx():
 def inc_table(smx):
     from synth_tools_amd import synthetic
     return synthetic.note_inc_table(smx.lib().note_to_inc)
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _soak_seed():
+    """SMX_SOAK_SEED=<int>: every numpy generator a test seeds itself is re-seeded with (seed XOR this value), so
+    that the parity tests (HIP path vs oracle on the same inputs) run on other data than the committed seeds give.
+    Off by default; tests that compare with committed fixtures do not draw their inputs from such generators."""
+    mix = os.environ.get("SMX_SOAK_SEED")
+    if not mix:
+        yield
+        return
+    import numpy as np
+    mix = int(mix, 0)
+    orig = np.random.default_rng
+
+    def seeded(seed=None):
+        return orig(seed if not isinstance(seed, int) else seed ^ mix)
+    np.random.default_rng = seeded
+    try:
+        yield
+    finally:
+        np.random.default_rng = orig
