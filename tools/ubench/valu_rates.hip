@@ -47,6 +47,7 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, uint32_t iters, uint32_
 {
     uint32_t r0 = threadIdx.x * seed, r1 = r0 ^ 0x1234u, r2 = r0 + 77u, r3 = r0 * 3u;
     uint32_t x0 = seed + threadIdx.x, x1 = x0 * 5u, x2 = x0 ^ 0xABCDu, x3 = x0 + 9u;
+    unsigned long long q0 = r0, q1 = r1, q2 = r2, q3 = r3, y0 = x0, y1 = x1, y2 = x2, y3 = x3;
     asm volatile("s_mov_b64 s[64:65], 0x5555" ::: "s64", "s65");
     for (uint32_t i = 0; i < iters; i++) {
         if constexpr (V == 0)  { REP16(OP4(F_ADD)) }
@@ -79,8 +80,18 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, uint32_t iters, uint32_
         if constexpr (V == 27) { REP16(OP4(F_LSHLREV)) }
         if constexpr (V == 28) { REP16(OP4(F_SUBREV)) }
         if constexpr (V == 29) { REP16(OP4(F_XOR)) }
+        if constexpr (V == 30) {       // 64-bit add: {counter, phase} += {0, inc} -- carry into the counter in one instruction
+            REP16(asm volatile("v_lshl_add_u64 %0, %0, 0, %4\n\tv_lshl_add_u64 %1, %1, 0, %5\n\t"
+                               "v_lshl_add_u64 %2, %2, 0, %6\n\tv_lshl_add_u64 %3, %3, 0, %7"
+                               : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(y0), "v"(y1), "v"(y2), "v"(y3));)
+        }
+        if constexpr (V == 31) {       // the same through the multiplier: D64 = a32 * 1 + c64
+            REP16(asm volatile("v_mad_u64_u32 %0, vcc, %4, 1, %0\n\tv_mad_u64_u32 %1, vcc, %5, 1, %1\n\t"
+                               "v_mad_u64_u32 %2, vcc, %6, 1, %2\n\tv_mad_u64_u32 %3, vcc, %7, 1, %3"
+                               : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3) : "vcc");)
+        }
     }
-    out[blockIdx.x * 1024 + threadIdx.x] = r0 + r1 + r2 + r3;
+    out[blockIdx.x * 1024 + threadIdx.x] = r0 + r1 + r2 + r3 + (uint32_t)((q0 + q1 + q2 + q3) >> 16);
 }
 
 template <int V>
@@ -111,5 +122,6 @@ int main()
     run<20>("v_cndmask_b32_e64 (sgpr mask)", out); run<21>("v_cmp_ne_u32 -> vcc", out); run<22>("v_cmp_ne_u32_e64 -> sgpr", out);
     run<23>("v_cmp + v_cndmask (2 instr)", out); run<24>("sub,or,ashr,and (4 instr)", out); run<25>("v_med3_u32", out);
     run<26>("v_min_u32", out); run<27>("v_lshlrev_b32", out); run<28>("v_subrev_u32", out); run<29>("v_xor_b32", out);
+    run<30>("v_lshl_add_u64", out); run<31>("v_mad_u64_u32", out);
     return 0;
 }
