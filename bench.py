@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # The kernels' inner loops in those units, per 64 units of work (one wave instruction each lane-op):
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
 ISSUE = {"saw_direct": 2.66 + 2.85 + 2.85,            # v_ashrrev + v_add (phase) + v_add (accumulate) per voice-sample
-         "saw_carry": (4 * 4.46 + 2 * 4.41) / 4,      # 4 v_add_co + 2 v_addc_co per 4 voice-samples (+ scalar popcounts)
+         "saw_carry": (4 * 4.50 + 2 * 4.64) / 4,      # 4 v_mad_u64_u32 ({wraps, phase} += inc) + 2 v_add3 per 4 voice-samples
          "pdm_tick_major": 10.0,                      # v_add_co + s_nop 1 + 2 v_writelane, measured as a sequence
          "pdm_stream": 4.46 + 4.41,                   # v_add_co + v_addc_co
          "dither_add": 2.85,

@@ -27,7 +27,7 @@
 //    keeps state0 + T*inc continuous -- the reference's "note_on does not reset the phase".
 //
 // Long blocks of big banks (> 32 frames, >= 2^30 voice-samples) take a second formulation
-// (saw_bank_carry_kernel) that needs 2 instead of 2.5 vector ops per voice-sample:
+// (saw_bank_carry_kernel) that needs 1.5 instead of 3 vector ops per voice-sample:
 // with u = state ^ 0x80000000 (offset binary) the arithmetic shift becomes a logical
 // one, (int)state >> 4 == (u >> 4) - 2^27, and because every term is a floor,
 //     sum_v (u_v >> 4) == (sum_v u_v - sum_v (u_v & 15)) >> 4        exactly.
@@ -35,9 +35,10 @@
 // W(t) = number of 32-bit wraps of all phases before frame t; the low nibbles
 // (u_v(t) & 15) == ((u_v(t0) & 15) + t*(inc_v & 15)) & 15 depend on 8 bits per voice,
 // so their sum comes from a 256-bin histogram.  Per voice-sample only the phase add
-// and the count of its carry-out remain: v_add_co + v_addc (two of four voices) or
-// v_add_co + s_bcnt1 on the carry mask (the other two: the scalar unit works beside
-// the vector unit).  Everything is reduced in integers, so the result is the same
+// and the count of its carry-out remain: one 64-bit add of {wraps so far, phase} += inc
+// per voice (the carry lands in the high word) and two v_add3 per four voices that add
+// the cumulative counts into the frame's counter (carry_step4_wide; carry_step4 is the
+// older loop over carry masks).  Everything is reduced in integers, so the result is the same
 // bits as the reference loop; a small second kernel combines the per-workgroup
 // partial sums into the int32 bus.
 //
@@ -363,6 +364,32 @@ __device__ __forceinline__ uint32_t carry_step4(uint32_t &u0, uint32_t &u1, uint
 #endif
 }
 
+// The same four voices as {wraps so far, phase} pairs: phase += inc as ONE 64-bit multiply-add whose carry lands in
+// the high word (v_mad_u64_u32 issues at the rate of one v_add_co: 4.5 cycles, tools/ubench/valu_rates.hip), and the
+// voices' CUMULATIVE wrap counts enter the frame's counter with two v_add3 -- 6 vector instructions per 4 voices and
+// frame like carry_step4, but none of them waits for an SGPR mask and nothing is left to the scalar unit
+// (tools/ubench/saw_v2_proto.hip: 21.1 vs 19.1-20.0 T voice-samples/s; in the kernel, stepping form pinned: 64 Mi
+// voices x 64 frames 225.6 -> 212 us, 16 Mi x 64 72.1 -> 65.2, 8 Mi x 128 79.1 -> 71.5, 256 Ki x 4096 78.5 -> 72.0;
+// two voices through pairs and two through masks + s_bcnt1 measured as well: better only for 64 Mi x 128, 385 vs 411).
+// The counters then hold cumulative counts; the caller turns them into per-frame counts once per launch.
+__device__ __forceinline__ void carry_step4_wide(unsigned long long &q0, unsigned long long &q1, unsigned long long &q2,
+                                                 unsigned long long &q3, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3,
+                                                 uint32_t &cnt)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %4, 1, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %5, 1, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %6, 1, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %7, 1, %3"
+        : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+        : "v"(i0), "v"(i1), "v"(i2), "v"(i3)
+        : "vcc");
+    cnt += (uint32_t)(q0 >> 32) + (uint32_t)(q1 >> 32);
+    cnt += (uint32_t)(q2 >> 32) + (uint32_t)(q3 >> 32);
+#else
+    (void)q0; (void)q1; (void)q2; (void)q3; (void)i0; (void)i1; (void)i2; (void)i3; (void)cnt;
+#endif
+}
 // floor(a / d) for a quotient known to be below 2^11, with ONE reciprocal per divisor shared by all quotients of a
 // voice: the estimate (float)a * rd, rd = rcp((float)d) * (1 - 2^-18), lies below the true ratio by less than
 // 2^-17.5 of it (three roundings of 2^-24 .. 2^-23 each against a bias of 2^-18), i.e. by less than 0.006 for ratios
@@ -392,7 +419,7 @@ __device__ __forceinline__ uint32_t div_small(uint32_t a, uint32_t d, float rd)
 // x 64 frames 236 -> 18x us -- but the loop runs as long as the busiest voice of the wave, so banks
 // with many high voices are slower this way (all voices at 12 wraps: 3x).  The finalize kernel
 // keeps the statistic that picks the form (mode_flag; see SAW_SCRATCH_HEADER).
-template <bool NT, bool MULTI, int TC, bool EVENTS>
+template <bool NT, bool MULTI, int TC, bool EVENTS, bool WIDE = false>
 __global__ __launch_bounds__(256)
 void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
                            SawPartial *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
@@ -517,6 +544,10 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // list is free for the next row
             __builtin_amdgcn_wave_barrier();
+        } else if constexpr (WIDE) {
+            unsigned long long q0 = u0, q1 = u1, q2 = u2, q3 = u3;       // high words: wraps so far in this chunk
+#pragma unroll
+            for (int t = 0; t < TC; t++) carry_step4_wide(q0, q1, q2, q3, a.x, a.y, a.z, a.w, cnt[t]);
         } else {
 #pragma unroll
             for (int t = 0; t < TC; t++) {
@@ -527,10 +558,15 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     }
 
     if constexpr (!EVENTS) {
+        if constexpr (WIDE) {
+            // the 64-bit forms counted cumulative wraps (frames 0..t): back to wraps AT frame t
+#pragma unroll
+            for (int t = TC - 1; t > 0; t--) cnt[t] -= cnt[t - 1];
+        }
         // per-lane counts -> M[t][lane]; per-wave scalar counts -> M[t][64]
 #pragma unroll
         for (int t = 0; t < TC; t++) atomicAdd(&M[t][lane], cnt[t]);
-        if (lane == 0) {
+        if (!WIDE && lane == 0) {
 #pragma unroll
             for (int t = 0; t < 32; t++) {
                 atomicAdd(&M[t][64], W[t] & 0xFFFFu);
@@ -1130,7 +1166,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                      (!cm && n_pad >= (1u << 23) && nframes >= 64);
     // (banks from 2^16 voices: 256 Ki voices x 4096 frames 70 -> 44 us, x 16384 frames 260 -> 120 us)
     if (nframes > 32 && n_pad >= (1u << 16) && big && d_scratch && !no_carry) {
-        // carry-count formulation: 2 vector ops per voice-sample
+        // carry-count formulation: 1.5 vector ops per voice-sample
         const uint32_t ngroups = n_pad / 4;
         const uint32_t gy = (nframes + 63) / 64;
         static const char *cg = getenv("SMX_SAW_CARRY_GRID");           // tuning override
@@ -1157,9 +1193,15 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             uint32_t gx_ev = ((cg ? (uint32_t)atoi(cg) : (gy == 1 ? 4096u : 8192u)) + gy - 1) / gy;
             if (gx_ev > (ngroups + 255) / 256) gx_ev = (ngroups + 255) / 256;
             uint32_t *ran_long = flag + 1;                    // which slot layout the launch filled
-#define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_, EV_, FLAG_)                                                   \
-    hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, EV_>), dim3((EV_) ? gx_ev : gx, gy),    \
+            static const bool wide = getenv("SMX_SAW_NO_WIDE") == nullptr;          // A/B switch: carry masks instead of 64-bit pairs
+#define SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, W_, FLAG_)                                                  \
+    hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, EV_, W_>), dim3((EV_) ? gx_ev : gx, gy),    \
                        dim3(256), 0, stream, d_inc, d_state_in, part, ngroups, tbase, FLAG_, ran_long)
+#define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_, EV_, FLAG_)                                                        \
+    do {                                                                                                      \
+        if ((EV_) || !wide) SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, false, FLAG_);                          \
+        else                SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, false, true, FLAG_);                         \
+    } while (0)
             const bool nt = n_pad >= (1u << 24);
             static const bool no_long = getenv("SMX_SAW_NO_LONG_EVENTS") != nullptr;          // A/B switch
             if (nframes >= SAW_LONG && !no_long) {
@@ -1196,6 +1238,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                 }
             }
 #undef SMX_CARRY_LAUNCH
+#undef SMX_CARRY_LAUNCH_W
             hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
                                d_bus_next, nframes, n_pad, flag, ran_long, host_flag);
             SMX_HIP(hipGetLastError());

@@ -90,6 +90,63 @@ void v2_k(const u32x4 *__restrict__ inc, const u32x4 *__restrict__ si, u32x4 *__
 }
 
 
+// Mixed: voices 0/1 step as {wraps so far, phase} += inc in one 64-bit multiply-add (the carry lands in the high
+// word), their cumulative counts enter the per-frame counter with one v_add3; voices 2/3 as before (v_add_co +
+// s_bcnt1).  VARIANT 1: all four voices through the 64-bit form (two v_add3 per frame).
+// NOTE: cnt[t] then holds CUMULATIVE carries (what the finalize kernel derives by a prefix sum anyway).
+template <int VARIANT>
+__global__ __launch_bounds__(256)
+void v5_k(const u32x4 *__restrict__ inc, const u32x4 *__restrict__ si, u32x4 *__restrict__ so,
+          uint32_t *__restrict__ dump, uint32_t ngroups)
+{
+    uint32_t cnt[64];
+    uint32_t W[32];
+#pragma unroll
+    for (int t = 0; t < 64; t++) cnt[t] = 0;
+#pragma unroll
+    for (int t = 0; t < 32; t++) W[t] = 0;
+    for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < ngroups; g += gridDim.x * 256u) {
+        u32x4 a = __builtin_nontemporal_load(&inc[g]);
+        u32x4 b = __builtin_nontemporal_load(&si[g]);
+        u32x4 o; o.x = b.x + 64u * a.x; o.y = b.y + 64u * a.y; o.z = b.z + 64u * a.z; o.w = b.w + 64u * a.w;
+        __builtin_nontemporal_store(o, &so[g]);
+        unsigned long long q0 = b.x ^ 0x80000000u, q1 = b.y ^ 0x80000000u, q2 = b.z ^ 0x80000000u, q3 = b.w ^ 0x80000000u;
+        uint32_t u2 = (uint32_t)q2, u3 = (uint32_t)q3;
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (VARIANT == 0) {
+                unsigned long long m2, m3;
+                asm("v_mad_u64_u32 %0, vcc, %6, 1, %0\n\t"
+                    "v_mad_u64_u32 %1, vcc, %7, 1, %1\n\t"
+                    "v_add_co_u32_e64 %2, %4, %2, %8\n\t"
+                    "v_add_co_u32_e64 %3, %5, %3, %9"
+                    : "+v"(q0), "+v"(q1), "+v"(u2), "+v"(u3), "=&s"(m2), "=&s"(m3)
+                    : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w) : "vcc");
+                const uint32_t c = (uint32_t)(__builtin_popcountll(m2) + __builtin_popcountll(m3));
+                W[t & 31] += (t < 32) ? c : (c << 16);
+                cnt[t] += (uint32_t)(q0 >> 32) + (uint32_t)(q1 >> 32);
+            } else {
+                asm("v_mad_u64_u32 %0, vcc, %4, 1, %0\n\t"
+                    "v_mad_u64_u32 %1, vcc, %5, 1, %1\n\t"
+                    "v_mad_u64_u32 %2, vcc, %6, 1, %2\n\t"
+                    "v_mad_u64_u32 %3, vcc, %7, 1, %3"
+                    : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                    : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w) : "vcc");
+                cnt[t] += (uint32_t)(q0 >> 32) + (uint32_t)(q1 >> 32);
+                cnt[t] += (uint32_t)(q2 >> 32) + (uint32_t)(q3 >> 32);
+            }
+#endif
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int t = 0; t < 64; t++) acc += cnt[t] * (t + 1);
+#pragma unroll
+    for (int t = 0; t < 32; t++) acc += W[t] * 3;
+    dump[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 template <int NV>
 __global__ __launch_bounds__(256)
 void v3_k(const u32x4 *__restrict__ inc, const u32x4 *__restrict__ si, u32x4 *__restrict__ so,
@@ -183,6 +240,9 @@ int main(int argc, char **argv) {
         float w2 = timeit([&] { hipLaunchKernelGGL(v3_k<2>, dim3(gx), dim3(256), 0, 0, (const u32x4 *)inc, (const u32x4 *)s0, (u32x4 *)s1, dump, ng); }, 10);
         float w1 = timeit([&] { hipLaunchKernelGGL(v3_k<1>, dim3(gx), dim3(256), 0, 0, (const u32x4 *)inc, (const u32x4 *)s0, (u32x4 *)s1, dump, ng); }, 10);
         float w4 = timeit([&] { hipLaunchKernelGGL(v3_k<4>, dim3(gx), dim3(256), 0, 0, (const u32x4 *)inc, (const u32x4 *)s0, (u32x4 *)s1, dump, ng); }, 10);
+        float m0 = timeit([&] { hipLaunchKernelGGL(v5_k<0>, dim3(gx), dim3(256), 0, 0, (const u32x4 *)inc, (const u32x4 *)s0, (u32x4 *)s1, dump, ng); }, 10);
+        float m1 = timeit([&] { hipLaunchKernelGGL(v5_k<1>, dim3(gx), dim3(256), 0, 0, (const u32x4 *)inc, (const u32x4 *)s0, (u32x4 *)s1, dump, ng); }, 10);
+        printf("grid %5d: mixed 64-bit (2 voices mad_u64 + add3, 2 add_co + s_bcnt) %.1f | all four 64-bit %.1f Gs/s\n", gx, n * 64.0 / m0 / 1e6, n * 64.0 / m1 / 1e6);
         printf("grid %5d: v2<2> %.1f | 2-pass NV2 %.1f NV1 %.1f NV4 %.1f Gs/s\n", gx, n * 64.0 / v2 / 1e6, n * 64.0 / w2 / 1e6, n * 64.0 / w1 / 1e6, n * 64.0 / w4 / 1e6);
     }
     return 0;
