@@ -5,11 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import synth_tools_amd as sta
 from synth_tools_amd import synthetic
 tab = synthetic.note_inc_table(sta.lib().note_to_inc)
-line = "carry_min_log2=%s:" % os.environ.get("SMX_SAW_CARRY_MIN_LOG2", "30")
+form = int(os.environ.get("SMX_EXPLORE_FORM", "0"))          # 0 AUTO, 1 STEPPING pinned
+line = "carry_min_log2=%s form=%d:" % (os.environ.get("SMX_SAW_CARRY_MIN_LOG2", "30"), form)
 for lg in (21, 22, 23, 24, 25):
     n = 1 << lg
     inc, st = synthetic.saw_bank(n, 1, tab)
     b = sta.SawBank(n); b.load(inc, st)
+    b.set_block_form(form)
     for nf in (64, 128):
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.04:
