@@ -54,14 +54,17 @@ void cproc_kernel(smx::CprocProgram prog, uint32_t *__restrict__ state,   // [no
                 : lds[(nd.in * 2) * 256 + tid];
             uint32_t *o = &lds[(k * 2 + 0) * 256 + tid];
             uint32_t *l = &lds[(k * 2 + 1) * 256 + tid];
-            if (nd.proc == 1) {                                 // acc, cproc.h:142-144
-                *o += in;
-            } else if (nd.proc == 3) {                          // gpin, hw_cproc_stm32f103.h:12-14: out = the input word
-                *o = in;
-            } else {                                            // edge, cproc.h:152-155
-                *o = (in != *l);
+            // acc (cproc.h:142-144): out += in;  gpin (hw_cproc_stm32f103.h:12-14): out = in;  edge (cproc.h:152-155):
+            // out = (in != last), last = in.  One wave-uniform branch per node (the edge's `last`); acc against gpin is
+            // a mask on the old `out`, not a branch: a three-way if/else here cost 17 % of the kernel (the
+            // structurizer's chain of uniform branches: 1 Mi instances x 256 ticks of the bp5 chain 600 -> 705 us)
+            const uint32_t keep = 0u - (uint32_t)(nd.proc == 1);
+            uint32_t x = in;
+            if (nd.proc == 2) {
+                x = (in != *l) ? 1u : 0u;
                 *l = in;
             }
+            *o = (*o & keep) + x;
         }
         if (out) out[(size_t)t * n_pad + inst] = lds[(out_node * 2) * 256 + tid];
     };
