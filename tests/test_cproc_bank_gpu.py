@@ -154,3 +154,25 @@ def test_dynamic_patcher(smx, orc):
         assert p.apply(PROC_GPOUT, [0]) == k
     assert p.apply(PROC_GPOUT, [0]) == PATCH_ALLOC_FAIL             # node table full (a bound of this build)
     p.close()
+
+
+@pytest.mark.parametrize("n_inputs", [1, 2, 5, 8, 9, 20])
+def test_input_staging_paths(smx, orc, n_inputs):
+    """Up to 8 input words per tick the kernel runs its double-buffered pipeline (chunks of 8 / n_inputs ticks); more
+    words take the single staging buffer.  Ragged tick counts, several calls, every input word used."""
+    from synth_tools_amd import PROC_ACC, PROC_EDGE, cproc_input
+    rng = np.random.default_rng(700 + n_inputs)
+    nodes = [(PROC_EDGE if w % 2 else PROC_ACC, cproc_input(w), 1 + w % 3) for w in range(n_inputs)]
+    nodes += [(PROC_ACC, int(rng.integers(0, n_inputs)), 3), (PROC_EDGE, n_inputs, 1)]
+    nodes = nodes[:32]
+    n = 777
+    bank = smx.CprocBank(n, nodes, n_inputs)
+    state = np.zeros((len(nodes), 2, n), np.uint32)
+    for nt in (1, 7, 8, 9, 33):
+        inp = rng.integers(0, 5, (nt, n_inputs, n)).astype(np.uint32)
+        g = rng.integers(0, 8, nt).astype(np.uint32)
+        got = bank.tick_n(inp, g)
+        want = _oracle_run(orc, nodes, n, n_inputs, state, inp, g, len(nodes) - 1)
+        assert np.array_equal(got, want), (n_inputs, nt)
+    assert np.array_equal(bank.read_state(), state)
+    bank.close()
