@@ -32,12 +32,14 @@
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <errno.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/types.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -93,6 +95,20 @@ static int n_ranks = 1, my_rank = 0;
 static int helper[8];
 struct rank_cmd { uint32_t nframes, nev; };          /* then 3 * nev bytes of events; nframes 0: events only */
 
+/* A helper that dies must end the client, loudly, wherever rank 0 is at that moment -- also inside an RCCL sum that
+ * the dead rank will never join (no watchdog could return from there).  SIGCHLD does that: the handler reaps, says so
+ * and leaves with status 1 (async-signal-safe calls only); a supervisor (jack_client.erl sees exit_status) starts a
+ * fresh process -- never a re-exec from a process that has touched the GPU.  SIGPIPE is ignored so that a write to a
+ * dead helper's pipe reports EPIPE here instead of killing the client silently. */
+static void on_sigchld(int sig) {
+    (void)sig;
+    int st;
+    if (waitpid(-1, &st, WNOHANG) > 0) {
+        static const char msg[] = "synth: a helper rank is gone\n";
+        if (write(2, msg, sizeof msg - 1) < 0) { /* nothing to do about it */ }
+        _exit(1);
+    }
+}
 static void write_all(int fd, const void *buf, size_t n) {
     const uint8_t *p = buf;
     while (n) {
@@ -169,6 +185,10 @@ static void helper_loop(int fd, uint32_t voices) {
         if (c.nev) { if (!read_all(fd, ev, 3u * c.nev)) break; ASSERT(0 == smx_bank_midi_events(bank, ev, c.nev)); }
         if (c.nframes) ASSERT(0 == smx_bank_run(bank, NULL, NULL, (int)c.nframes));
     }
+    /* rank 0 closed the pipe (or is gone): release the shard and its communicator; should a peer that has already
+       left keep the teardown waiting, SIGALRM's default action ends this process after 5 s */
+    alarm(5);
+    smx_bank_destroy(bank);
     _exit(0);
 }
 static jack_port_t *midi_in, *audio_out; /* linux/synth.c:214-221 */
@@ -233,6 +253,7 @@ int main(int argc, char **argv) {
         /* fork the helper ranks FIRST: no process may have touched the GPU when it forks */
         n_ranks = atoi(getenv("SYNTH_RANKS"));
         ASSERT(n_ranks >= 1 && n_ranks <= 8);
+        if (n_ranks > 1) { signal(SIGPIPE, SIG_IGN); signal(SIGCHLD, on_sigchld); }
         for (int r = 1; r < n_ranks; r++) {
             int fd[2];
             ASSERT(0 == pipe(fd));
@@ -242,6 +263,7 @@ int main(int argc, char **argv) {
                 close(fd[1]);
                 for (int k = 1; k < r; k++) close(helper[k]);      /* the other helpers' pipes are not ours */
                 close(0);
+                signal(SIGCHLD, SIG_DFL);
                 my_rank = r;
                 helper_loop(fd[0], voices);
             }

@@ -177,6 +177,25 @@ def load_ref_pmeas():
     return lib
 
 
+def load_ref_pwmosc():
+    """OSC_HARD_SYNC / pwm_phase / pwm_speed / pwm_update of the reference's stm32f103/mod_pdm.c (:159-175),
+    compiled verbatim into oracle/_ref/libref_pwmosc.so (None if absent).  The reference keeps ONE oscillator
+    in globals: ref_pwm_set() loads it."""
+    so = os.path.join(_HERE, "_ref", "libref_pwmosc.so")
+    if os.path.isdir("/root/reference"):
+        build()
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    lib.ref_pwm_update.restype = C.c_uint32
+    lib.ref_pwm_get_phase.restype = C.c_uint32
+    lib.ref_pwm_get_speed.restype = C.c_uint32
+    lib.ref_pwm_control_div.restype = C.c_uint32
+    lib.ref_pwm_set.argtypes = [C.c_uint32, C.c_uint32]
+    lib.ref_pwmosc_run.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
 class quiet_stderr:
     """Silences fd 2 (the reference's note_to_inc LOGs every call, linux/synth.c:123)."""
     def __enter__(self):

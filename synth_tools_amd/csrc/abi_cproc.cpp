@@ -159,9 +159,12 @@ static int patch_reserve(smx_patch *p, uint32_t nodes)
     uint32_t *d = nullptr;
     const size_t row = (size_t)c->n_pad * 4;
     SMX_HIP(hipMalloc((void **)&d, (size_t)cap * 2 * row));
-    SMX_HIP(hipMemset(d, 0, (size_t)cap * 2 * row));                        // state initialises to zero (:98)
+    // Cleared and copied ON THE BANK'S STREAM: the null stream's hipMemset returns before the fill has run and a
+    // non-blocking stream does not wait for it (the ring of the saw bank once met its own clear).
+    SMX_HIP(hipMemsetAsync(d, 0, (size_t)cap * 2 * row, c->stream));        // state initialises to zero (:98)
     if (c->d_state) {
-        SMX_HIP(hipMemcpy(d, c->d_state, (size_t)p->cap_nodes * 2 * row, hipMemcpyDeviceToDevice));
+        SMX_HIP(hipMemcpyAsync(d, c->d_state, (size_t)p->cap_nodes * 2 * row, hipMemcpyDeviceToDevice, c->stream));
+        SMX_HIP(hipStreamSynchronize(c->stream));                           // the old rows are read before they are freed
         SMX_HIP(hipFree(c->d_state));
     }
     c->d_state = d;

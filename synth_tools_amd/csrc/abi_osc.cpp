@@ -194,8 +194,12 @@ extern "C" smx_clock *smx_clock_create(uint32_t n, int device)
               hipMalloc((void **)&c->d_hperiod, bytes) == hipSuccess &&
               hipMalloc((void **)&c->d_phase, bytes) == hipSuccess &&
               hipMalloc((void **)&c->d_pol, bytes) == hipSuccess &&
-              hipMemset(c->d_hperiod, 0, bytes) == hipSuccess && hipMemset(c->d_phase, 0, bytes) == hipSuccess &&
-              hipMemcpy(c->d_pol, ones.data(), bytes, hipMemcpyHostToDevice) == hipSuccess;
+              // cleared and filled on the bank's own stream, then waited for: nothing of this object is ever
+              // ordered by the null stream (which a non-blocking stream does not wait for)
+              hipMemsetAsync(c->d_hperiod, 0, bytes, c->stream) == hipSuccess &&
+              hipMemsetAsync(c->d_phase, 0, bytes, c->stream) == hipSuccess &&
+              hipMemcpyAsync(c->d_pol, ones.data(), bytes, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+              hipStreamSynchronize(c->stream) == hipSuccess;
     if (!ok) {
         set_error("smx_clock_create: HIP allocation failed: %s", hipGetErrorString(hipGetLastError()));
         smx_clock_destroy(c);

@@ -122,6 +122,8 @@ struct smx_bank {
     uint32_t bus_zeroed[NBUS] = {};              // leading frames known to be zero
     int bus_cur = 0;
     uint32_t bus_cap = 0;                        // = stride of the ring, in frames
+    uint32_t ring_alloc = 0;                     // frames per slot the ring's memory (and h_bus) is sized for (>= bus_cap)
+    static constexpr uint32_t RING_MIN_FRAMES = 4096;
     uint32_t scratch_cap = 0;                    // frames d_scratch is sized for
     int32_t *h_bus = nullptr;                    // pinned
     // pipelined block mode (smx_bank_set_block_mode): the bus of block k is copied to pinned
@@ -136,6 +138,11 @@ struct smx_bank {
     uint32_t *h_form = nullptr;
     uint32_t form_seen = 0xFFFFFFFFu, form_seq = 0;
     int form_stable = 0;
+    // Every long block carries the host's own number for it (long_tag) and the device echoes that number with
+    // its pick.  A pick counts only when its block was LAUNCHED after the last note event / reload
+    // (tag > form_min_tag): finalizations that were still in flight when the increments changed describe the
+    // old bank and must not pin a form for the new one.
+    uint32_t long_tag = 0, form_min_tag = 0;
     static constexpr int FORM_STABLE = 4;
     int32_t *h_pipe[2] = {nullptr, nullptr};
     uint32_t pipe_cap = 0;
@@ -186,6 +193,7 @@ static void bank_form_unpin(smx_bank *b)
 {
     b->form_seen = 0xFFFFFFFFu;
     b->form_stable = 0;
+    b->form_min_tag = b->long_tag;           // picks of the blocks launched so far are about the old increments
 }
 
 // Does the (global) voice number belong to this bank?  -> its local index
@@ -215,9 +223,20 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
     SMX_HIP(hipStreamSynchronize(b->stream));
     if (b->comm_stream) SMX_HIP(hipStreamSynchronize(b->comm_stream));
     const uint32_t cap = smx::round_up(n, 64);
-    if (b->d_ring) SMX_HIP(hipFree(b->d_ring));
-    b->d_ring = nullptr;
-    SMX_HIP(hipMalloc((void **)&b->d_ring, (size_t)smx_bank::NBUS * cap * 4));
+    // The ring's MEMORY is sized for the usual JACK block lengths from the start (RING_MIN_FRAMES per slot), so a
+    // first callback that is longer than anything seen before only re-strides it: no hipFree / hipMalloc /
+    // hipHostMalloc on the real-time path.  The STRIDE stays tight (the longest block seen, rounded
+    // up to 64 frames) so that a group of blocks is one short contiguous all-reduce.
+    const uint32_t alloc = cap < smx_bank::RING_MIN_FRAMES ? smx_bank::RING_MIN_FRAMES : smx::round_up(cap, 4096);
+    if (alloc > b->ring_alloc) {
+        if (b->d_ring) SMX_HIP(hipFree(b->d_ring));
+        b->d_ring = nullptr;
+        SMX_HIP(hipMalloc((void **)&b->d_ring, (size_t)smx_bank::NBUS * alloc * 4));
+        if (b->h_bus) SMX_HIP(hipHostFree(b->h_bus));
+        b->h_bus = nullptr;
+        SMX_HIP(hipHostMalloc((void **)&b->h_bus, (size_t)alloc * 4, hipHostMallocDefault));
+        b->ring_alloc = alloc;
+    }
     // (stream-ordered: hipMemset on the null stream is asynchronous to the host and b->stream, a non-blocking
     // stream, would not wait for it -- the first block's kernel could meet a buffer that is cleared under it)
     SMX_HIP(hipMemsetAsync(b->d_ring, 0, (size_t)smx_bank::NBUS * cap * 4, b->stream));
@@ -226,9 +245,6 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
         b->bus_zeroed[i] = cap;
         b->comm_pending[i] = false;
     }
-    if (b->h_bus) SMX_HIP(hipHostFree(b->h_bus));
-    b->h_bus = nullptr;
-    SMX_HIP(hipHostMalloc((void **)&b->h_bus, (size_t)cap * 4, hipHostMallocDefault));
     // partial-sum slots of the slot / carry formulations: sized for 4096 frames at least, so
     // that the usual block lengths never reallocate them
     const uint32_t scap = smx::round_up(n < 4096 ? 4096 : n, 4096);
@@ -359,15 +375,18 @@ static int bank_exchange_free_maps(smx_bank *b, const uint32_t *inc)
     if (nr == 1) {
         all = mine;
     } else {
-        uint64_t *d_send = nullptr, *d_recv = nullptr;
-        SMX_HIP(hipMalloc((void **)&d_send, w * 8));
-        SMX_HIP(hipMalloc((void **)&d_recv, (size_t)nr * w * 8));
-        SMX_HIP(hipMemcpy(d_send, mine.data(), w * 8, hipMemcpyHostToDevice));
+        // one staging allocation [send | recv], released on every way out (a failed collective load must not
+        // leave device memory behind on each retry); copies and the gather are ordered on the comm stream
+        struct Staging {
+            uint64_t *d = nullptr;
+            ~Staging() { if (d) (void)hipFree(d); }
+        } st;
+        SMX_HIP(hipMalloc((void **)&st.d, ((size_t)nr + 1) * w * 8));
+        uint64_t *d_send = st.d, *d_recv = st.d + w;
+        SMX_HIP(hipMemcpyAsync(d_send, mine.data(), w * 8, hipMemcpyHostToDevice, b->comm_stream));
         SMX_NCCL(ncclAllGather(d_send, d_recv, w * 8, ncclUint8, b->comm, b->comm_stream));
+        SMX_HIP(hipMemcpyAsync(all.data(), d_recv, (size_t)nr * w * 8, hipMemcpyDeviceToHost, b->comm_stream));
         SMX_HIP(hipStreamSynchronize(b->comm_stream));
-        SMX_HIP(hipMemcpy(all.data(), d_recv, (size_t)nr * w * 8, hipMemcpyDeviceToHost));
-        SMX_HIP(hipFree(d_send));
-        SMX_HIP(hipFree(d_recv));
     }
     b->free_map.load_leaf_words(0, all.data(), all.size());
     return SMX_OK;
@@ -376,7 +395,7 @@ static int bank_exchange_free_maps(smx_bank *b, const uint32_t *inc)
 // Declare this bank the shard [first_voice, first_voice + n) of a global bank of total_voices voices.
 extern "C" int smx_bank_shard(smx_bank *b, uint32_t first_voice, uint32_t total_voices)
 {
-    if (!b || (b->n & 63) || total_voices < b->n || first_voice > total_voices - b->n || (first_voice % b->n) ||
+    if (!b || b->n == 0 || (b->n & 63) || total_voices < b->n || first_voice > total_voices - b->n || (first_voice % b->n) ||
         (total_voices % b->n)) {
         set_error("smx_bank_shard: first=%u total=%u for a bank of %u voices (equal shards, a multiple of 64 voices each)",
                   first_voice, total_voices, b ? b->n : 0);
@@ -516,9 +535,17 @@ static int bank_comm_flush(smx_bank *b)
     SMX_HIP(hipEventRecord(b->ev_kernel[last], b->stream));
     SMX_HIP(hipStreamWaitEvent(b->comm_stream, b->ev_kernel[last], 0));
     bool run = true;
-    for (int k = 1; k < b->ar_count; k++) run = run && b->ar_queue[k] == b->ar_queue[k - 1] + 1;
+    size_t frames = (size_t)b->ar_frames[0];
+    for (int k = 1; k < b->ar_count; k++) {
+        run = run && b->ar_queue[k] == b->ar_queue[k - 1] + 1;
+        frames += (size_t)b->ar_frames[k];
+    }
+    const size_t count = (size_t)(last - first) * b->bus_cap + (size_t)b->ar_frames[b->ar_count - 1];
+    // The stride only grows (the longest block ever seen): after one 4096-frame block a group of eight 1-frame
+    // blocks would be 7 x 4096 + 1 words on xGMI instead of 8.  A range that is mostly gap goes as
+    // one grouped launch of per-block sums instead (still one collective launch, a few bytes each).
+    if (count > 4 * frames && count > 1024) run = false;
     if (run) {
-        const size_t count = (size_t)(last - first) * b->bus_cap + (size_t)b->ar_frames[b->ar_count - 1];
         SMX_NCCL(ncclAllReduce(b->d_bus[first], b->d_bus[first], count, ncclInt32, ncclSum, b->comm, b->comm_stream));
     } else {
         SMX_NCCL(ncclGroupStart());
@@ -599,18 +626,21 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
     rv = bank_bus_advance(b, (uint32_t)n, &bi, &bnext);
     if (rv) return rv;
     int form = b->block_form;
+    if (n > 32) b->long_tag++;                                           // this block's number (echoed with its pick)
     if (form == SMX_FORM_AUTO && n > 32 && b->h_form) {
         const volatile uint32_t *hf = b->h_form;                         // whatever has landed: no sync
         const uint32_t seq = hf[1], seen = hf[0];
         if (seq != b->form_seq) {                                        // a long block was finalized since the last look
             b->form_seq = seq;
-            if (seen == b->form_seen) b->form_stable++; else { b->form_seen = seen; b->form_stable = 0; }
+            if ((int32_t)(seq - b->form_min_tag) > 0) {                  // ... and it was launched after the last note event
+                if (seen == b->form_seen) b->form_stable++; else { b->form_seen = seen; b->form_stable = 0; }
+            }
         }
         if (b->form_stable >= smx_bank::FORM_STABLE && b->form_seen <= 1u)
             form = b->form_seen ? SMX_FORM_EVENTS : SMX_FORM_STEPPING;
     }
     rv = smx::launch_saw_bank(b->d_inc, b->d_state0, b->d_bus[bi], b->d_bus[bnext], b->n_pad, (uint32_t)n,
-                              b->elapsed, b->d_scratch, form, b->h_form, b->stream, &b->pend);
+                              b->elapsed, b->d_scratch, form, b->h_form, b->long_tag, b->stream, &b->pend);
     if (rv) return rv;
     b->elapsed += (uint32_t)n;             // mod 2^32, like the phases
     b->bus_zeroed[bi] = 0;                 // now holds this block's sums

@@ -750,13 +750,15 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
 
 // End of a long block: the exact statistics of this launch (header words above) and the host's mirror
 // {pick, number of long blocks finalized}.
+// host_tag: the HOST's number of this long block (it counts the long blocks it launches): the host ignores picks
+// whose tag is not younger than its last note event, so a finalization that was in flight when the increments
+// changed can never pin a form.
 __device__ __forceinline__ void saw_stats_publish(uint32_t *__restrict__ hdr, uint32_t *__restrict__ host_flag,
-                                                  uint32_t pick)
+                                                  uint32_t pick, uint32_t host_tag)
 {
     hdr[0] = pick;
-    const uint32_t seq = hdr[2] + 1u;
-    hdr[2] = seq;
-    if (host_flag) { host_flag[0] = pick; host_flag[1] = seq; }   // pinned host copy: lets the host skip the form that would return at once
+    hdr[2] = hdr[2] + 1u;                                         // long blocks finalized since the header was cleared
+    if (host_flag) { host_flag[0] = pick; host_flag[1] = host_tag; }   // pinned host copy: lets the host skip the form that would return at once
 }
 // I = the sum of all increments of the bank (header words [4..5], exact: see SAW_SCRATCH_HEADER)
 __device__ __forceinline__ unsigned long long saw_stats_sum_inc(const uint32_t *__restrict__ hdr)
@@ -778,7 +780,7 @@ template <uint32_t TL>
 __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ partial, int32_t *__restrict__ bus,
                                                   int32_t *__restrict__ bus_next, uint32_t nframes,
                                                   uint32_t nvoices, uint32_t *__restrict__ mode_flag,
-                                                  uint32_t *__restrict__ host_flag)
+                                                  uint32_t *__restrict__ host_flag, uint32_t host_tag)
 {
     constexpr uint32_t FPT = TL / 256;
     __shared__ uint32_t Hs[256], Wsum[4];
@@ -850,7 +852,7 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ 
     }
     if (blockIdx.x == 0 && tid == 0 && mode_flag) {
         const uint32_t f = (MXs < SAW_EVENTS_MAX_INC && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
-        saw_stats_publish(mode_flag, host_flag, f);
+        saw_stats_publish(mode_flag, host_flag, f, host_tag);
     }
 }
 
@@ -861,16 +863,17 @@ __global__ __launch_bounds__(256)
 void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
                               int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
                               uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag,
-                              const uint32_t *__restrict__ ran_long, uint32_t *__restrict__ host_flag)
+                              const uint32_t *__restrict__ ran_long, uint32_t *__restrict__ host_flag,
+                              uint32_t host_tag)
 {
     // which slot layout did this launch fill?  (written by the main kernel that ran, stable here)
     if (ran_long && *ran_long != 0u) {
         if (*ran_long == 1u) {
             if (blockIdx.x * 256u < nframes)
-                saw_finalize_long<256>(reinterpret_cast<SawPartialL<256> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag);
+                saw_finalize_long<256>(reinterpret_cast<SawPartialL<256> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag, host_tag);
         } else {
             if (blockIdx.x * 1024u < nframes)
-                saw_finalize_long<1024>(reinterpret_cast<SawPartialL<1024> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag);
+                saw_finalize_long<1024>(reinterpret_cast<SawPartialL<1024> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag, host_tag);
         }
         return;
     }
@@ -935,7 +938,7 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         if (blockIdx.x == 0 && t == 0 && mode_flag) {
             const uint32_t m = max(max(Mx[0], Mx[1]), max(Mx[2], Mx[3]));
             const uint32_t fl = (m < SAW_EVENTS_MAX_INC && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
-            saw_stats_publish(mode_flag, host_flag, fl);
+            saw_stats_publish(mode_flag, host_flag, fl, host_tag);
         }
     }
 }
@@ -1147,8 +1150,8 @@ int launch_saw_flush(SawPending *pend, hipStream_t stream) { return flush_pendin
 
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
-                    void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream,
-                    SawPending *pend)
+                    void *d_scratch, int long_block_form, uint32_t *host_flag, uint32_t host_tag,
+                    hipStream_t stream, SawPending *pend)
 {
     if (n_pad == 0 || (n_pad & 1023) || nframes == 0) {
         set_error("launch_saw_bank: n_pad=%u nframes=%u", n_pad, nframes);
@@ -1240,7 +1243,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
 #undef SMX_CARRY_LAUNCH
 #undef SMX_CARRY_LAUNCH_W
             hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
-                               d_bus_next, nframes, n_pad, flag, ran_long, host_flag);
+                               d_bus_next, nframes, n_pad, flag, ran_long, host_flag, host_tag);
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         }

@@ -61,11 +61,11 @@ size_t saw_scratch_region_bytes(uint32_t max_frames);
 int launch_saw_flush(SawPending *pend, hipStream_t stream);
 // long_block_form: SMX_FORM_AUTO / SMX_FORM_STEPPING / SMX_FORM_EVENTS (include/synth_mi355x.h)
 // host_flag: two pinned (device-visible) words that receive, after every long block, the form the device
-// would pick next (0 stepping, 1 events) and the number of long blocks finalized so far; or NULL.
+// would pick next (0 stepping, 1 events) and host_tag, the caller's own number of this block; or NULL.
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state0, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
-                    void *d_scratch, int long_block_form, uint32_t *host_flag, hipStream_t stream,
-                    SawPending *pend = nullptr);      // pend == nullptr: every launch folds its own slots
+                    void *d_scratch, int long_block_form, uint32_t *host_flag, uint32_t host_tag,
+                    hipStream_t stream, SawPending *pend = nullptr);      // pend == nullptr: every launch folds its own slots
 // leading bytes of the scratch area that hold the formulation flag (zero: stepping form) and the bank's sum of
 // increments; after clearing them (new increments) launch_saw_sum_inc recomputes the sum
 size_t saw_scratch_header_bytes();

@@ -4,7 +4,8 @@ for the pdm.h vectors): `python tests/golden/make_golden.py`.
  survey_known_answers.json  hand-entered DATA: the known-answers SURVEY.md
                             (§8 a-5, Appendix A.2/A.3) recorded from the
                             reference, plus the one KAT the reference holds
-                            (comment at stm32f103/mod_pdm.c:43-47, X=3 row).
+                            (comment at stm32f103/mod_pdm.c:30-53: the power-of-two period
+                            table, the X=3 rows and the X=5 accumulator row).
  pdm_h_reference.npz        outputs of the REAL stm32f103/pdm.h (oracle/_ref,
                             compiled from /root/reference where it lies).
  synth_run_derived.npz      regression vectors of THIS repo's restatement of
@@ -14,6 +15,10 @@ for the pdm.h vectors): `python tests/golden/make_golden.py`.
                             float bits + final voice[] + note2voice[] of scripted sequences.
  pmeas_reference.npz        struct pmeas_state after every call of the REAL pmeas_update
                             (stm32f103/pmeas.h:64-108, oracle/_ref/libref_pmeas.so).
+ pwmosc_reference.npz       duty bytes and phases of the REAL pwm_update / OSC_HARD_SYNC
+                            (stm32f103/mod_pdm.c:159-175, oracle/_ref/libref_pwmosc.so): the reference's
+                            default speed 256*13 and five others, 70 000 ticks each, hard syncs at
+                            scripted ticks.
 """
 import json
 import os
@@ -30,7 +35,8 @@ from synth_tools_amd import synthetic  # noqa: E402
 def survey_known_answers():
     d = {
         "_provenance": "SURVEY.md §8 a-5 and Appendix A.2/A.3 (values observed from the reference "
-                       "during the survey) and the comment KAT at stm32f103/mod_pdm.c:43-47",
+                       "during the survey) and the comment KATs at stm32f103/mod_pdm.c:30-38 (period table), "
+                       ":43-47 (X=3 rows), :49-53 (X=5 accumulator row)",
         "note_tab": [594573364, 629928536, 667386036, 707070875, 749115497, 793660223,
                      840853716, 890853479, 943826384, 999949221, 1059409296, 1122405051],
         "note_to_inc": {"0": 731558, "16": 1843410, "32": 4645104, "48": 11704929,
@@ -45,6 +51,17 @@ def survey_known_answers():
                                              "pdm2_s": [0x76594000, 0x7676A000]},
         "mod_pdm_comment_kat_3bit": {"X": 3, "A": [0, 3, 6, 1, 4, 7, 2, 5, 0],
                                      "C": [1, 0, 0, 1, 0, 0, 1, 0, 1]},
+        # the complementary row of the same comment (mod_pdm.c:49-53, X = 5 = 8 - 3).  Only its A row is data: the
+        # C row printed under it (1 0 1 0 0 1 0 0 1) is NOT what add-with-carry gives (that is 1 0 1 0 1 1 0 1 1;
+        # the comment mirrors the X = 3 pulses instead) -- SURVEY §4 -- and is kept here only to say so.
+        "mod_pdm_comment_kat_3bit_x5": {"X": 5, "A": [0, 5, 2, 7, 4, 1, 6, 3, 0],
+                                        "C_as_printed_not_reproducible": [1, 0, 1, 0, 0, 1, 0, 0, 1]},
+        # the power-of-two table of the same comment (mod_pdm.c:30-38): resolution N = 2^B, input X a power of two
+        # -> one pulse every P samples.  Rows as [X, P] in units of N (X = N/d -> P = d); the last row (X = N,
+        # P = 1) is outside a B-bit input and is listed for completeness only.
+        "mod_pdm_comment_period_table": {"rows_X_over_N__P": [["1/N", "N"], ["2/N", "N/2"], ["4/N", "N/4"],
+                                                                ["1/2", 2], ["1", 1]],
+                                         "testable_log2_X_32bit": [20, 21, 22, 24, 27, 29, 30, 31]},
         "mod_pdm_two_channel_derived": {"setpoint": [2000000000, 0x40000000], "ticks": 6,
                                         "bsrr": [0x300000, 0x300000, 0x200010, 0x100020,
                                                  0x200010, 0x300000],
@@ -224,10 +241,56 @@ def pmeas_reference():
     np.savez_compressed(os.path.join(HERE, "pmeas_reference.npz"), **out)
 
 
+def pwmosc_cases():
+    """(phase0, speed, sync ticks) per case.  70 000 ticks: the `phase >> 9` feedback makes the ramp
+    accelerate, so the 24-bit mask (mod_pdm.c:162) is crossed tens to hundreds of times per case."""
+    rng = np.random.default_rng(0x5EED0F)
+    nt = 70000
+    c = {}
+    c["default_256x13"] = (0, None, np.array([], np.int64))              # speed = the reference's own initialiser
+    c["default_synced"] = (0, None, np.sort(rng.choice(nt, 40, replace=False)))
+    c["speed_1"] = (0, 1, np.array([5, 6, 7, 30000], np.int64))          # slowest: feedback dominates late
+    c["speed_65536_phase_mid"] = (0x7FFFFF, 65536, np.sort(rng.choice(nt, 200, replace=False)))
+    c["speed_max24"] = (0xFFFFFF, 0xFFFFFF, np.sort(rng.choice(nt, 25, replace=False)))
+    c["speed_big_u32"] = (0x123456, 0xDEADBEEF, np.arange(0, nt, 4097))  # speed above the mask: wraps mod 2^32 first
+    return nt, c
+
+
+def pwmosc_reference():
+    ref = oracle.load_ref_pwmosc()
+    if ref is None:
+        print("oracle/_ref/libref_pwmosc.so absent and /root/reference not present: skipped")
+        return
+    nt, cases = pwmosc_cases()
+    out = {"_provenance": np.array("duty = pwm_update() and pwm_phase after every tick of "
+                                   "/root/reference/stm32f103/mod_pdm.c:159-175 compiled verbatim (oracle/Makefile ref); "
+                                   "sync[t]: OSC_HARD_SYNC() before tick t"),
+           "nticks": np.uint32(nt), "default_speed": np.uint32(ref.ref_pwm_get_speed()),
+           "default_phase": np.uint32(ref.ref_pwm_get_phase()), "control_div": np.uint32(ref.ref_pwm_control_div())}
+    for name, (phase0, speed, sync_ticks) in cases.items():
+        if speed is None:
+            speed = int(out["default_speed"])
+        ref.ref_pwm_set(int(phase0), int(speed))
+        sync = np.zeros(nt, np.uint8)
+        sync[sync_ticks] = 1
+        duty = np.zeros(nt, np.uint8)
+        ph = np.zeros(nt, np.uint32)
+        ref.ref_pwmosc_run(nt, sync.ctypes.data, duty.ctypes.data, ph.ctypes.data)
+        out[name + "_phase0"] = np.uint32(phase0)
+        out[name + "_speed"] = np.uint32(speed)
+        out[name + "_sync_ticks"] = np.asarray(sync_ticks, np.int64)
+        out[name + "_duty"] = duty
+        out[name + "_phase_every16"] = ph[15::16].copy()          # pwm_phase after ticks 15, 31, ... (fixture size)
+        out[name + "_phase_end"] = np.uint32(ph[-1])
+        out[name + "_wraps"] = np.uint32(np.count_nonzero(ph[1:] < ph[:-1]))   # crossings of the 24-bit mask + syncs
+    np.savez_compressed(os.path.join(HERE, "pwmosc_reference.npz"), **out)
+
+
 if __name__ == "__main__":
     survey_known_answers()
     pdm_h_reference()
     synth_run_derived()
     synth_c_reference()
     pmeas_reference()
+    pwmosc_reference()
     print(sorted(os.listdir(HERE)))

@@ -133,6 +133,40 @@ def test_pdm_comment_kat(orc, kat):
     assert accu[0] == 0 and bits[0] == k["C"][0]
 
 
+def test_pdm_comment_kat_x5_accumulator_row(orc, kat):
+    """The complementary row (mod_pdm.c:49-53, X = 5 = 8 - 3): the accumulator sequence is data; the carry row
+    printed under it is not what add-with-carry produces and the oracle must NOT reproduce it."""
+    k = kat["mod_pdm_comment_kat_3bit_x5"]
+    sp = np.array([k["X"] << 29], np.uint32)
+    accu = np.array([k["A"][0] << 29], np.uint32)
+    carries = []
+    for i in range(1, len(k["A"])):
+        bits = np.zeros(1, np.uint32)
+        orc.orc_pdm_tick(sp, accu, 1, 0, bits)
+        assert accu[0] >> 29 == k["A"][i] and accu[0] & 0x1FFFFFFF == 0
+        carries.append(int(bits[0]))
+    assert carries == [0, 1, 0, 1, 1, 0, 1, 1]                       # 5 pulses in 8 ticks = X / N
+    assert carries != k["C_as_printed_not_reproducible"][1:]
+    # "the same waveform, but in reverse" (mod_pdm.c:49-50): X=5's pulses are X=3's gaps read backwards
+    x3 = kat["mod_pdm_comment_kat_3bit"]["C"][1:]
+    assert [1 - c for c in carries] == x3[::-1]
+
+
+def test_pdm_comment_period_table(orc, kat):
+    """mod_pdm.c:30-38: X a power of two -> one pulse every N / X ticks (N = 2^32 here)."""
+    for lg in kat["mod_pdm_comment_period_table"]["testable_log2_X_32bit"]:
+        period = 1 << (32 - lg)
+        nt = 3 * period if period > 2 else 16
+        sp = np.array([1 << lg], np.uint32)
+        accu = np.zeros(1, np.uint32)
+        bits = oracle.pdm_run(orc, sp, accu, nt)[:, 0]
+        assert np.flatnonzero(bits).tolist() == list(range(period - 1, nt, period)), lg
+    # X = 1: period N = 2^32 -- the one pulse lies where the accumulator wraps
+    sp = np.array([1], np.uint32)
+    accu = np.array([0xFFFFFFFD], np.uint32)
+    assert oracle.pdm_run(orc, sp, accu, 8)[:, 0].tolist() == [0, 0, 1, 0, 0, 0, 0, 0]
+
+
 def test_pdm_two_channel_bsrr_derived(orc, kat):
     k = kat["mod_pdm_two_channel_derived"]
     sp = np.array(k["setpoint"], np.uint32)

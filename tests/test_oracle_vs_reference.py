@@ -1,9 +1,10 @@
 """CPU: the oracle of the HEADLINE path against the reference itself.
 
-linux/synth.c:27-208 (note tables, allocator, sum_tick_saw/square, synth_run) and
-stm32f103/pmeas.h:64-108 (pmeas_update) compile verbatim with system headers alone
+linux/synth.c:27-208 (note tables, allocator, sum_tick_saw/square, synth_run),
+stm32f103/pmeas.h:64-108 (pmeas_update) and stm32f103/mod_pdm.c:159-175 (OSC_HARD_SYNC, pwm_update)
+compile verbatim with system headers alone
 (oracle/Makefile `ref` streams those line ranges into gcc; nothing is stubbed).  Their
-outputs are committed as tests/golden/synth_c_reference.npz / pmeas_reference.npz
+outputs are committed as tests/golden/synth_c_reference.npz / pmeas_reference.npz / pwmosc_reference.npz
 (generator: tests/golden/make_golden.py) and the oracle must reproduce them bit for bit;
 when oracle/_ref is present (build container, and the GPU box: the .so travels) the oracle
 is also compared live on random operation sequences.
@@ -81,7 +82,70 @@ def test_oracle_pmeas_reproduces_reference_traces(orc):
     assert published > 20                                          # the publish branch (pmeas.h:85-91) ran
 
 
+def pwmosc_cases(g):
+    return sorted(k[:-5] for k in g.files if k.endswith("_duty"))
+
+
+def test_oracle_pwm_update_reproduces_reference_outputs(orc):
+    """Row a-8b: orc_pwm_update / orc_pwmosc_run == the reference's pwm_update + OSC_HARD_SYNC
+    (mod_pdm.c:159-175 compiled verbatim), 70 000 ticks per case."""
+    g = np.load(os.path.join(GOLD, "pwmosc_reference.npz"))
+    assert int(g["default_speed"]) == 256 * 13 and int(g["default_phase"]) == 0       # mod_pdm.c:160-161
+    assert int(g["control_div"]) == 256                                              # mod_pdm.c:164
+    nt = int(g["nticks"])
+    names = pwmosc_cases(g)
+    assert len(names) >= 6 and nt >= 70000
+    for name in names:
+        phase = np.array([g[name + "_phase0"]], np.uint32)
+        speed = np.array([g[name + "_speed"]], np.uint32)
+        sync = np.zeros((nt, 1), np.uint32)
+        sync[g[name + "_sync_ticks"], 0] = 1
+        # tick by tick through orc_pwm_update for the phases ...
+        ph = int(phase[0])
+        p1 = np.zeros(1, np.uint32)
+        seen = []
+        duty1 = np.zeros(nt, np.uint8)
+        for t in range(nt):
+            if sync[t, 0]:
+                ph = 0
+            p1[0] = ph
+            duty1[t] = orc.orc_pwm_update(p1, int(speed[0])) & 0xFF
+            ph = int(p1[0])
+            if t % 16 == 15:
+                seen.append(ph)
+        assert np.array_equal(duty1, g[name + "_duty"]), name
+        assert seen == g[name + "_phase_every16"].tolist(), name
+        assert ph == int(g[name + "_phase_end"]), name
+        # ... and the bank loop the GPU tests use as their oracle
+        duty = np.zeros((nt, 1), np.uint8)
+        orc.orc_pwmosc_run(phase, speed, 1, sync.ctypes.data, nt, duty.ctypes.data)
+        assert np.array_equal(duty[:, 0], g[name + "_duty"]), name
+        assert int(phase[0]) == int(g[name + "_phase_end"]), name
+        assert int(g[name + "_wraps"]) >= 19, name          # the 24-bit mask (mod_pdm.c:162) is crossed many times
+
+
 # ---- live, when the compiled reference is present ----------------------------------------
+def test_live_random_pwm_updates_against_compiled_mod_pdm_c(orc):
+    ref = oracle.load_ref_pwmosc()
+    if ref is None:
+        pytest.skip("oracle/_ref/libref_pwmosc.so not built (needs /root/reference)")
+    rng = np.random.default_rng(159175)
+    for case in range(40):
+        nt = 5000
+        phase0 = int(rng.integers(0, 1 << 24))
+        speed = int(rng.integers(0, 1 << int(rng.integers(1, 33))))
+        sync = (rng.random(nt) < rng.choice([0.0, 0.001, 0.05])).astype(np.uint8)
+        ref.ref_pwm_set(phase0, speed)
+        want = np.zeros(nt, np.uint8)
+        ref.ref_pwmosc_run(nt, sync.ctypes.data, want.ctypes.data, None)
+        phase = np.array([phase0], np.uint32)
+        got = np.zeros((nt, 1), np.uint8)
+        sync_words = np.ascontiguousarray(sync.astype(np.uint32).reshape(nt, 1))     # kept alive across the call
+        orc.orc_pwmosc_run(phase, np.array([speed], np.uint32), 1, sync_words.ctypes.data, nt, got.ctypes.data)
+        assert np.array_equal(got[:, 0], want), case
+        assert int(phase[0]) == ref.ref_pwm_get_phase(), case
+
+
 def test_live_random_ops_against_compiled_synth_c(orc):
     ref = oracle.load_ref_synth()
     if ref is None:

@@ -1,8 +1,11 @@
 """GPU parity: oscillator bank (pwm_update + hard sync of mod_pdm.c:159-175; osc ISR
 of mod_osc.c:47-74 with pmeas.h:64-100) against the CPU oracle, bit-exact.
-These reference sources are ARM/HAL code that cannot be built here: the oracle is a
-restatement ("parity unpinned")."""
+pwm_update / OSC_HARD_SYNC are pinned by the reference itself (mod_pdm.c:159-175 compiled verbatim into
+oracle/_ref/libref_pwmosc.so, outputs committed as tests/golden/pwmosc_reference.npz); pmeas_update by
+pmeas.h compiled the same way; the sub-oscillator toggle and the ISR around them (mod_osc.c: HAL code
+that cannot be built here) are a restatement ("parity unpinned")."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -34,6 +37,34 @@ def test_pwmosc_parity_with_hard_sync(smx, orc, n):
             assert np.array_equal(got, want), "n=%d nt=%d" % (n, nt)
     gph, gsp = bank.read_pwm()
     assert np.array_equal(gph, op) and np.array_equal(gsp, speed)
+    bank.close()
+
+
+def test_pwmosc_kernel_reproduces_reference_outputs(smx):
+    """Row a-8b on the GPU against the REFERENCE's outputs (no oracle in between): every case of
+    tests/golden/pwmosc_reference.npz is one oscillator of a bank, 70 000 ticks, hard syncs as a bit matrix."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pwmosc_reference.npz"))
+    names = sorted(k[:-5] for k in g.files if k.endswith("_duty"))
+    nt, n = int(g["nticks"]), len(names)
+    assert n >= 6
+    bank = smx.OscBank(n)
+    ph0, sp0 = bank.read_pwm()
+    assert ph0.tolist() == [int(g["default_phase"])] * n and sp0.tolist() == [int(g["default_speed"])] * n
+    bank.load_pwm(np.array([g[k + "_phase0"] for k in names], np.uint32),
+                  np.array([g[k + "_speed"] for k in names], np.uint32))
+    sync = np.zeros((nt, 1), np.uint32)
+    for c, k in enumerate(names):
+        sync[g[k + "_sync_ticks"], 0] |= np.uint32(1 << c)
+    # in three calls of ragged length, reading the phases back at a tick the fixture holds
+    cuts = [0, 16 * 1000, 16 * 1000 + 16 * 2001, nt]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        duty = bank.tick_n(b - a, np.ascontiguousarray(sync[a:b]))
+        for c, k in enumerate(names):
+            assert np.array_equal(duty[:, c], g[k + "_duty"][a:b]), (k, a)
+        ph = bank.read_pwm()[0]
+        for c, k in enumerate(names):
+            want = int(g[k + "_phase_end"]) if b == nt else int(g[k + "_phase_every16"][b // 16 - 1])
+            assert int(ph[c]) == want, (k, b)
     bank.close()
 
 

@@ -59,6 +59,39 @@ def test_comment_kat_on_gpu(smx):
     bank.close()
 
 
+def test_comment_kat_x5_accumulator_row_on_gpu(smx):
+    """mod_pdm.c:49-53: A: 0 5 2 7 4 1 6 3 0 for X = 5 on a 3-bit accumulator (scaled by 2^29), read back
+    with smx_pdm_read after every tick; and "the same waveform, but in reverse" against the X = 3 row."""
+    kat = json.load(open(os.path.join(GOLD, "survey_known_answers.json")))
+    k = kat["mod_pdm_comment_kat_3bit_x5"]
+    bank = smx.PdmBank(1)
+    bank.load(np.array([k["X"] << 29], np.uint32), np.array([k["A"][0] << 29], np.uint32))
+    carries = []
+    for want in k["A"][1:]:
+        carries.append(int(bank.tick_n(1)[0, 0]))
+        assert int(bank.read()[1][0]) == want << 29
+    bank.close()
+    assert [1 - c for c in carries] == kat["mod_pdm_comment_kat_3bit"]["C"][1:][::-1]
+
+
+def test_comment_period_table_on_gpu(smx):
+    """mod_pdm.c:30-38: X = 2^k -> one pulse every 2^(32-k) ticks; all testable rows as channels of ONE bank
+    (plus X = 1 with the accumulator three ticks before its wrap), 12 288 ticks in ragged calls."""
+    lgs = json.load(open(os.path.join(GOLD, "survey_known_answers.json")))["mod_pdm_comment_period_table"]["testable_log2_X_32bit"]
+    sp = np.array([1 << lg for lg in lgs] + [1], np.uint32)
+    ac = np.array([0] * len(lgs) + [0xFFFFFFFD], np.uint32)
+    bank = smx.PdmBank(len(sp))
+    bank.load(sp, ac)
+    nt = 3 * 4096
+    bits = np.concatenate([bank.tick_n(k) for k in (1, 63, 64, 4000, nt - 4128)])[:, 0]
+    for c, lg in enumerate(lgs):
+        period = 1 << (32 - lg)
+        assert np.flatnonzero((bits >> np.uint32(c)) & 1).tolist() == list(range(period - 1, nt, period)), lg
+    assert np.flatnonzero((bits >> np.uint32(len(lgs))) & 1).tolist() == [2]
+    assert bank.read()[1].tolist() == [(nt << lg) & 0xFFFFFFFF for lg in lgs] + [nt - 3]
+    bank.close()
+
+
 def test_c3_full_size_1m_channels(smx, orc):
     """BASELINE config 3: 1 Mi channels.  Size-independent properties with dither = 0:
     accu' = T*setpoint mod 2^32 and pulses(channel) = floor(T*setpoint / 2^32) exactly;
