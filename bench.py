@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-verify", action="store_true", help="skip the bus checks (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--repeats", type=int, default=9,
+                    help="the timed region of --steps steps is run this many times; the line reports the median")
     return ap.parse_args()
 
 
@@ -191,6 +193,32 @@ def poly_block_numpy(a, nframes):
             bus[i, 0] = int((q * pl).sum())
             bus[i, 1] = int((q * pr).sum())
     return wrap_i32(bus)
+
+
+def pwm2_block_numpy(st, dither, nt, div_count, div_log=12, sh=24):
+    """The firmware's order-2 noise-shaped PWM channel (mod_pdm_pwm.c:108-143 with pdm2_update, pdm.h:32-40, and
+    control_update, mod_controlrate.c:28-40) for `nt` ticks, vectorised over the channels of `st` (a dict of uint32
+    arrays: setpoint pos0 vel0 pos1 vel1 s1 s2).  -> (duty uint8[nt, n], state after).  All arithmetic mod 2^32."""
+    sp, pos0, vel0 = st["setpoint"].copy(), st["pos0"].copy(), st["vel0"].copy()
+    pos1, vel1, s1, s2 = st["pos1"].copy(), st["vel1"].copy(), st["s1"].copy(), st["s2"].copy()
+    duty = np.zeros((nt, len(sp)), np.uint8)
+    div = 1 << div_log
+    with np.errstate(over="ignore"):
+        for t in range(nt):
+            trigger = div_count == 0
+            if trigger:                                    # PDM_COPY_LINE, mod_pdm_pwm.c:118-119
+                pos0, vel0 = pos1.copy(), vel1.copy()
+            pos0 = pos0 + vel0                             # glide :95-98
+            q = s2 >> np.uint32(sh)                        # pdm2_update: the output is the quantised LAST state
+            a = (q << np.uint32(sh)) + np.uint32(dither[t])
+            s1 = s1 + (pos0 - a)
+            s2 = s2 + (s1 - a)
+            duty[t] = q.astype(np.uint8)
+            div_count = (div_count + 1) % div
+            if trigger:                                    # control_update runs after the tick that triggered it
+                pos1 = pos1 + (vel1 << np.uint32(div_log))
+                vel1 = ((sp - pos1).view(np.int32) >> div_log).view(np.uint32)
+    return duty, {"setpoint": sp, "pos0": pos0, "vel0": vel0, "pos1": pos1, "vel1": vel1, "s1": s1, "s2": s2}
 
 
 def roof(alg_bytes, ms, units=None, issue_cycles=None):
@@ -520,18 +548,67 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         for _ in range(20):
             w.tick_n_async(nt, True)
         ms = w.timer_stop() / 20
+        checked = None
+        if verify:
+            # one more launch with a known dither stream, placed so that a control-rate boundary (line copy +
+            # control_update) falls inside it: a slice of channels tick by tick against the numpy statement of the
+            # firmware's channel (duty bytes and the shaper's state), and EVERY channel's glide state in closed form
+            nc, first = 256, 100
+            w.div_count = (1 << 12) - first
+            before = w.read()
+            dith = synthetic.dither_stream(nc, 11, 0x3FF)                  # mod_pdm_pwm.c:127 mask
+            duty = w.tick_n(nc, dith)
+            after = w.read()
+            sl = np.r_[0:1024, n // 2 - 512:n // 2 + 512, n - 1024:n]
+            want_duty, want = pwm2_block_numpy({k: v[sl] for k, v in before.items()}, dith, nc, (1 << 12) - first)
+            ok = np.array_equal(duty[:, sl], want_duty) and all(np.array_equal(after[k][sl], want[k]) for k in want)
+            with np.errstate(over="ignore"):
+                pos1 = before["pos1"] + (before["vel1"] << np.uint32(12))
+                ok = ok and np.array_equal(after["pos0"], before["pos1"] + np.uint32(nc - first) * before["vel1"]) \
+                    and np.array_equal(after["vel0"], before["vel1"]) and np.array_equal(after["pos1"], pos1) \
+                    and np.array_equal(after["vel1"], ((before["setpoint"] - pos1).view(np.int32) >> 12).view(np.uint32))
+            if not ok or w.div_count != nc - first:
+                sys.exit("bench.py: PWM CHECK FAILED: duty bytes / shaper state of the slice or the bank's glide state differ")
+            checked = ("duty + shaper state of %d channels x %d ticks == numpy statement of mod_pdm_pwm.c's channel "
+                       "(oracle-pinned shaper: pdm.h), glide state of all %d channels == closed form across a "
+                       "control-rate boundary" % (len(sl), nc, n))
         w.close()
         e = {"workload": "noise-shaped PWM bank (pdm2+glide), %d channels, %d ticks/launch, dither seeded" % (n, nt),
              "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
              "ms_per_step": round(ms, 4), "roofline": roof(52.0 * n + float(nt) * n, ms, n * nt, ISSUE["pwm2"]),
-             "verified": None}
+             "verified": checked}
         e["hbm_frac"] = e["roofline"]["hbm_frac"]
         out.append(e)
     if "c4" in legs:
-        # BASELINE config 4: 256 Ki poly voices (saw + 1-pole LPF + ADSR + stereo mix; build-defined)
-        n = 1 << 18
+        # BASELINE config 4: 256 Ki poly voices (saw + 1-pole LPF + ADSR + stereo mix; build-defined), 64-frame blocks.
+        # SURVEY 8d's scenario: T = 48 000 samples (750 blocks), every voice's gate on for the first half and off for the
+        # second, envelopes at rest at t = 0, rates log-uniform 1 ms .. 1 s -- so attacks, decays and releases are in
+        # progress for most of the run (the kernel's general envelope path), not only the holds of a settled bank.
+        n, nblk = 1 << 18, 750
         pb = sta.PolyBank(n)
         arrs = synthetic.poly_bank(n, 0x5EED0004, tab)
+        on = np.ones(n, np.uint32)
+        off = np.zeros(n, np.uint32)
+
+        def scenario(timed):
+            pb.load(**dict(arrs, gate=on))
+            total = 0.0
+            for half, gate in enumerate((on, off)):
+                if half:
+                    pb.load(gate=gate)                       # the control-rate input changes between two blocks
+                if timed:
+                    pb.timer_start()
+                for _ in range(nblk // 2):
+                    pb.run_async(64)
+                if timed:
+                    total += pb.timer_stop()
+                else:
+                    pb.sync()
+            return total / (2 * (nblk // 2))
+        for _ in range(3):
+            scenario(False)                                   # ~30 ms of untimed blocks (clock ramp: time_saw)
+        ms_run = min(scenario(True) for _ in range(3))
+        # the settled bank (random gates, every envelope holding): round 2's number, for continuity
         pb.load(**arrs)
         settle(lambda: pb.run_async(64), pb.sync)
         pb.timer_start()
@@ -541,21 +618,152 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         ms = pb.timer_stop() / reps
         checked = None
         if verify:
-            cur = pb.read()
-            cur["gate"] = arrs["gate"]
-            want = poly_block_numpy(cur, 64)
-            got, _ = pb.run(64)
-            if not np.array_equal(got.reshape(64, 2).astype(np.int64), want):
-                sys.exit("bench.py: POLY CHECK FAILED: the stereo bus differs from the numpy statement of DESIGN 3.5")
-            checked = "stereo bus == numpy statement of the build's own definition (not reference parity)"
+            # a block in the middle of the attacks and decays (20 blocks after the gates went on) and one of the settled bank
+            for what, gate, blocks in (("envelopes moving", on, 20), ("settled", arrs["gate"], 0)):
+                if blocks:
+                    pb.load(**dict(arrs, gate=gate))
+                    for _ in range(blocks):
+                        pb.run_async(64)
+                cur = pb.read()
+                cur["gate"] = gate
+                want = poly_block_numpy(cur, 64)
+                got, _ = pb.run(64)
+                if not np.array_equal(got.reshape(64, 2).astype(np.int64), want):
+                    sys.exit("bench.py: POLY CHECK FAILED (%s): the stereo bus differs from the numpy statement of DESIGN 3.5" % what)
+            checked = "stereo bus == numpy statement of the build's own definition (not reference parity), with envelopes moving and settled"
         pb.close()
-        e = {"workload": "c4: poly bank (saw+LPF+ADSR, stereo; build-defined), %d voices, 64 frames/step" % n,
-             "value": round(n * 64 / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(ms, 5),
-             "roofline": roof(60.0 * n + 64 * 8, ms, n * 64, ISSUE["poly"]), "verified": checked}
-        e["roofline"]["bound"] = "vector issue + LDS atomics (19 mixed int/fp32 instructions per voice-sample; profiles/r02_counters.json)"
-        e["hbm_frac"] = e["roofline"]["hbm_frac"]
-        out.append(e)
+        for what, t in (("the 48 000-sample run of SURVEY 8d (gates on for T/2: attacks, decays, releases in progress), mean of 750 blocks", ms_run),
+                        ("settled bank (every envelope holding)", ms)):
+            e = {"workload": "c4: poly bank (saw+LPF+ADSR, stereo; build-defined), %d voices, 64 frames/step, %s" % (n, what),
+                 "value": round(n * 64 / (t * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(t, 5),
+                 "roofline": roof(60.0 * n + 64 * 8, t, n * 64, ISSUE["poly"]), "verified": checked}
+            e["roofline"]["bound"] = "vector issue at 4 waves per SIMD (256 Ki voices = 16 waves per CU) + launch floor; profiles/"
+            e["hbm_frac"] = e["roofline"]["hbm_frac"]
+            out.append(e)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# N > 1: the legs that only a run over several GPUs can measure (every rank makes the same calls: SPMD)
+# ---------------------------------------------------------------------------------------------
+def gather_floats(rdzv, values):
+    """-> list over ranks of the ranks' float lists."""
+    import struct
+    parts = rdzv.allgather(struct.pack("<%dd" % len(values), *values))
+    return [list(struct.unpack("<%dd" % len(values), p)) for p in parts]
+
+
+def multi_gpu_legs(sta, synthetic, tab, rdzv, rank, world, local, verify, L):
+    """BASELINE config 5 AS WRITTEN on the communicator: 1 Mi voices per GPU (8 Mi over 8 GPUs), per-GPU int32 mix,
+    RCCL sum (linux/synth.c:172-179 sharded).
+      (i)   throughput mode (run_async + allreduce_async) at 1 and 64 frames per step with 1 / 8 / 16 blocks per
+            collective: Gsamples/s over all ranks, per-GPU %HBM, collectives issued;
+      (ii)  the same shard through the synchronous and the pipelined smx_bank_run: wall microseconds per block;
+      (iii) collectives alone (256 B / 2 KB / 32 KB sums, no kernel in between): the measured latency L that
+            DESIGN 4's budget had to assume;
+    every timed loop bracketed by barrier + device synchronize on both sides, MAX over ranks; every leg's bus
+    (summed over ranks) checked against the closed form.  Returns (entries, collective probe) on every rank."""
+    V = 1 << 20
+    inc, st = synthetic.saw_bank(V, 0x5EED0C05 + 0x1000 * rank, tab)
+    c5 = Saw(sta, V, inc, st, device=local)
+    bank = c5.bank
+    uid = rdzv.broadcast(sta.comm_unique_id().tobytes() if rank == 0 else b"")
+    bank.comm_init(rank, world, np.frombuffer(uid, np.uint8).copy())
+    out = []
+
+    def bracket(steps, body):
+        """-> (max over ranks of the wall seconds, per-rank HIP-event ms per step)"""
+        rdzv.barrier()
+        L.smx_device_synchronize(local)
+        t0 = time.perf_counter()
+        bank.timer_start()
+        for _ in range(steps):
+            body()
+        kms = bank.timer_stop() / steps
+        bank.sync()
+        L.smx_device_synchronize(local)
+        rdzv.barrier()
+        dt = time.perf_counter() - t0
+        per_rank = gather_floats(rdzv, [dt, kms])
+        return max(p[0] for p in per_rank), [p[1] for p in per_rank]
+
+    def check_run(frames, pipelined):
+        """smx_bank_run's own return value (sum over ranks; one block late when pipelined) == closed form."""
+        t_first = c5.t
+        bus, _ = bank.run(frames)
+        c5.t += frames
+        if pipelined:
+            bus, _ = bank.run(frames)                  # hands out the block launched by the call before
+            c5.t += frames
+        want = saw_bus_closed_form(c5.inc, c5.state0, t_first, list(range(frames)))
+        parts = rdzv.allgather(want.astype("<i8").tobytes())
+        want = wrap_i32(sum(np.frombuffer(p, "<i8") for p in parts))
+        if not rdzv.all_ok(bool(np.array_equal(bus.astype(np.int64), want))):
+            sys.exit("bench.py: BUS CHECK FAILED (c5 shard, smx_bank_run, %d frames, %s)"
+                     % (frames, "pipelined" if pipelined else "sync"))
+
+    # (i) throughput mode
+    for frames in (1, 64):
+        steps = 400 if frames == 1 else 200
+        for group in (1, 8, 16):
+            bank.set_comm_group(group)
+
+            def step():
+                c5.run_async(frames)
+                bank.allreduce_async(frames)
+            for _ in range(20):
+                step()
+            bank.sync()
+            c0 = bank.comm_stats()
+            dt, kms = bracket(steps, step)
+            c1 = bank.comm_stats()
+            if verify:
+                c5.verify(frames, "c5 as written, %d frames, group %d" % (frames, group), rdzv=rdzv, comm=True,
+                          pick=None if frames <= 8 else [0, frames // 2, frames - 1])
+            ms = dt / steps * 1e3
+            e = saw_entry("c5 as written: %d x 1048576 voices (1 Mi per GPU), %d frame(s)/step, throughput mode, "
+                          "%d block(s) per collective" % (world, frames, group), V, frames, ms, "saw_direct",
+                          {"n_gpus": world, "comm_group": group,
+                           "collectives_issued": int(c1[0] - c0[0]), "block_sums_carried": int(c1[1] - c0[1]),
+                           "kernel_ms_per_rank": {"min": round(min(kms), 5), "max": round(max(kms), 5)},
+                           "timing": "wall, barrier + device sync on both sides, max over ranks"})
+            e["value"] = round(world * V * frames / (ms * 1e-3) / 1e9, 2)         # whole job
+            e["max_voices_48k"] = int(world * V * frames / (ms * 1e-3) / 48000)
+            e["verified"] = "bus summed over %d ranks == closed form" % world if verify else None
+            out.append(e)
+    bank.set_comm_group(8)
+    # (ii) smx_bank_run as the JACK callback calls it: synchronous, then pipelined
+    for pipelined in (False, True):
+        bank.set_block_mode(pipelined)
+        for frames in (1, 64):
+            for _ in range(10):
+                bank.run(frames)
+            c5.t += 10 * frames
+            steps = 200
+
+            def block():
+                bank.run(frames)
+            dt, kms = bracket(steps, block)
+            c5.t += steps * frames
+            if verify:
+                check_run(frames, pipelined)
+            out.append({"workload": "c5 shard through smx_bank_run (%s), %d x 1048576 voices, %d frame(s)/block"
+                                    % ("pipelined: block k-1 handed out while k runs" if pipelined else "synchronous", world, frames),
+                        "n_gpus": world, "us_per_block": round(dt / steps * 1e6, 2), "unit": "us per block (wall, max over ranks)",
+                        "value": round(world * V * frames * steps / dt / 1e9, 2), "value_unit": "Gsamples/s",
+                        "verified": "returned bus (sum over %d ranks) == closed form" % world if verify else None})
+    bank.set_block_mode(False)
+    # (iii) the collective alone
+    probe = []
+    for words in (64, 512, 8192):
+        us_sync, us_queued = bank.comm_probe(words, 100)
+        per_rank = gather_floats(rdzv, [us_sync, us_queued])
+        probe.append({"bytes": words * 4, "int32_words": words,
+                      "collective_us": round(max(p[0] for p in per_rank), 2),
+                      "collective_us_queued": round(max(p[1] for p in per_rank), 2)})
+    rdzv.barrier()
+    bank.close()
+    return out, probe
 
 
 # ---------------------------------------------------------------------------------------------
@@ -604,20 +812,29 @@ def run_rank(a):
             bank.allreduce_async(a.frames)
     bank.sync()
 
-    rdzv.barrier()
-    L.smx_device_synchronize(local)
-    t0 = time.perf_counter()
-    bank.timer_start()
-    for _ in range(a.steps):
-        saw.run_async(a.frames)
-        if comm:
-            bank.allreduce_async(a.frames)
-    kernel_ms = bank.timer_stop() / a.steps        # HIP events on the kernel's stream
-    bank.sync()                                    # issues what is still queued, both streams idle
-    L.smx_device_synchronize(local)
-    rdzv.barrier()
-    dt = time.perf_counter() - t0
-    dt, kernel_ms = rdzv.max_floats([dt, kernel_ms])
+    # The timed region: EXACTLY --steps steps between barrier + device synchronize on both sides, max over ranks --
+    # run --repeats times back to back; the line reports the MEDIAN region (and the fastest and slowest beside it):
+    # one 1.6 ms sample on a pool whose boxes and processes differ by 1-7 % is fragile.
+    regions = []
+    for _ in range(max(1, a.repeats)):
+        rdzv.barrier()
+        L.smx_device_synchronize(local)
+        t0 = time.perf_counter()
+        bank.timer_start()
+        for _ in range(a.steps):
+            saw.run_async(a.frames)
+            if comm:
+                bank.allreduce_async(a.frames)
+        k_ms = bank.timer_stop() / a.steps         # HIP events on the kernel's stream
+        bank.sync()                                # issues what is still queued, both streams idle
+        L.smx_device_synchronize(local)
+        rdzv.barrier()
+        d = time.perf_counter() - t0
+        per_rank = gather_floats(rdzv, [d, k_ms])
+        regions.append((max(p[0] for p in per_rank), max(p[1] for p in per_rank), [p[1] for p in per_rank]))
+    regions.sort(key=lambda r: r[0])
+    dt, kernel_ms, kernel_ms_ranks = regions[len(regions) // 2]
+    dt_min, dt_max = regions[0][0], regions[-1][0]
 
     # the timed kernel's only output is the bus: one more step, compared with the closed form
     checked = 0
@@ -625,6 +842,9 @@ def run_rank(a):
         checked = saw.verify(a.frames, "headline, %d voices x %d frames" % (a.voices, a.frames), rdzv=rdzv, comm=comm,
                              pick=None if a.frames <= 8 else sorted({0, a.frames // 2, a.frames - 1}))
     collectives, block_sums = bank.comm_stats() if comm else (0, 0)
+    mgpu = None
+    if comm and not a.no_also:
+        mgpu = multi_gpu_legs(sta, synthetic, tab, rdzv, rank, world, local, not a.no_verify, L)
 
     if rank == 0:
         vs = world * a.voices * a.frames * a.steps / dt
@@ -641,6 +861,10 @@ def run_rank(a):
             "value": round(vs / 1e9, 3), "unit": "Gsamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 5),
+            "ms_per_step_min": round(dt_min / a.steps * 1e3, 5), "ms_per_step_max": round(dt_max / a.steps * 1e3, 5),
+            "repeats": len(regions),
+            "timing": "median of %d timed regions of %d steps each (barrier + device synchronize on both sides of "
+                      "every region, max over ranks); value and ms_per_step are the median region's" % (len(regions), a.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "saw voice bank resident in HBM, %d voices/GPU x %d frame(s)/step "
@@ -675,6 +899,15 @@ def run_rank(a):
         }
         if comm:
             line["collectives"] = {"issued": collectives, "block_sums_carried": block_sums}
+            line["roofline"]["kernel_ms_per_rank"] = {"min": round(min(kernel_ms_ranks), 5), "max": round(max(kernel_ms_ranks), 5)}
+        if mgpu is not None:
+            # N > 1 (or a 1-rank communicator forced for a rehearsal): BASELINE config 5 as written + the collective alone
+            line["also"] = mgpu[0]
+            line["collective_probe"] = {"what": "ncclAllReduce(int32, sum) of a bus of that size on the bank's communicator, "
+                                                "no kernel in between, 100 repetitions, max over ranks: collective_us = each one "
+                                                "waited for (launch + collective + stream sync), collective_us_queued = back to "
+                                                "back (the comm stream's own rate)",
+                                        "sizes": mgpu[1]}
         if world == 1 and not a.no_cpu:
             ref = cpu_baseline_reference(inc, state, min(a.cpu_seconds, 4.0))
             single, par = cpu_baseline_saw(inc, state, a.frames, a.cpu_seconds)
@@ -685,7 +918,7 @@ def run_rank(a):
         if world == 1 and not a.no_also:
             legs = [x for x in a.legs.split(",") if x]
             also = also_workloads(sta, synthetic, tab, saw, a.voices, legs, not a.no_verify)
-            line["also"] = also
+            line["also"] = also + (mgpu[0] if mgpu is not None else [])
             cfg = [e for e in also if e["workload"].startswith(("c2:", "c3:", "c4:", "c5 "))]
             line["config"]["baseline_configs_vs_50pct_hbm"] = {
                 "meet": [e["workload"] for e in cfg if e["roofline"]["hbm_frac"] >= 0.5],

@@ -195,7 +195,18 @@ int smx_bank_allreduce_async(smx_bank *b, int n);
 int smx_bank_set_comm_group(smx_bank *b, int blocks);
 /* Counters: collectives issued so far and the block sums they carried. */
 int smx_bank_comm_stats(const smx_bank *b, unsigned long long *collectives, unsigned long long *block_sums);
-/* Copy the (reduced) bus to the host and convert as linux/synth.c:180. */
+/* Measurement aid, no reference counterpart: the cost of ONE bus sum of n_words int32 (1..2^20) on this bank's
+ * communicator with no kernel in between, averaged over `reps` all-reduces.  *us_sync: host time per all-reduce when
+ * each is waited for (what a synchronous smx_bank_run pays on top of its kernel); *us_queued: per all-reduce when
+ * `reps` are queued back to back and waited for once (what a group of kernels has to hide in throughput mode).
+ * Collective: every rank calls it with the same arguments.  Issues and waits for everything queued before. */
+int smx_bank_comm_probe(smx_bank *b, uint32_t n_words, uint32_t reps, float *us_sync, float *us_queued);
+/* The (reduced) bus of the last block on the host, converted as linux/synth.c:180.  Blocks of up to 4096 frames
+ * come back without a copy engine: the stream's last (one-workgroup) kernel writes the sums to coherent pinned host
+ * memory and then a sequence number, and this call polls that number -- bounded: if the GPU has not answered within
+ * SMX_PUBLISH_TIMEOUT_MS (environment, default 10000) the call returns SMX_E_NOGPU instead of spinning forever.
+ * SMX_NO_PUBLISH=1 selects the older hipMemcpyAsync + hipStreamSynchronize path (same bits).  The drop-in
+ * synth_run(struct synth *) uses the same hand-over from a single launch (its 64 voices are kernel arguments). */
 int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n);
 
 /* ======================================================================== */

@@ -110,6 +110,7 @@ ABI = [
     ("smx_bank_comm_ranks", C.c_int, [_P]),
     ("smx_bank_set_comm_group", C.c_int, [_P, C.c_int]),
     ("smx_bank_comm_stats", C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    ("smx_bank_comm_probe", C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("smx_bank_fetch", C.c_int, [_P, _P, _P, C.c_int]),
     ("smx_pdm_create", _P, [C.c_uint32, C.c_int]),
     ("smx_pdm_destroy", None, [_P]),
@@ -326,6 +327,12 @@ class SawBank:
 
     def set_comm_group(self, blocks):
         _check(lib().smx_bank_set_comm_group(self._h, blocks), "smx_bank_set_comm_group")
+
+    def comm_probe(self, n_words, reps=50):
+        """(us per all-reduce when each is waited for, us per all-reduce queued back to back); collective."""
+        a, b = C.c_float(), C.c_float()
+        _check(lib().smx_bank_comm_probe(self._h, n_words, reps, C.byref(a), C.byref(b)), "smx_bank_comm_probe")
+        return a.value, b.value
 
     def comm_stats(self):
         """(collectives issued, block sums they carried)."""

@@ -129,7 +129,7 @@ static void dropin_run(struct synth *x, float *vec, int n, bool square)
         SMX_ASSERT_OK(smx_bank_load(g_dropin, inc, state), "sum_tick_square: load");
         SMX_ASSERT_OK(smx_bank_run_square(g_dropin, vec, n), "sum_tick_square: run");
     } else {
-        SMX_ASSERT_OK(smx_bank_load_run(g_dropin, inc, state, vec, nullptr, n), "synth_run: run");
+        SMX_ASSERT_OK(smx::bank_dropin_run(g_dropin, inc, state, vec, n), "synth_run: run");
     }
     // the advanced phases in closed form (an off voice does not advance): no read-back needed
     for (int v = 0; v < 64; v++) x->voice[v].note_state = state[v] + (uint32_t)n * inc[v];

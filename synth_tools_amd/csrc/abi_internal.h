@@ -12,6 +12,9 @@ static inline float bus_to_float(int32_t sum)
 }
 
 
+// abi_saw.cpp: struct synth's 64 voices for one block (the drop-in synth_run's device path).  Not exported.
+namespace smx { int bank_dropin_run(smx_bank *b, const uint32_t *inc, const uint32_t *state, float *vec, int n); }
+
 // Grow-only device scratch buffer (waits for the stream before reallocating).
 static inline int dev_reserve(void **ptr, size_t *cap, size_t need, hipStream_t stream)
 {

@@ -9,8 +9,11 @@ struct smx_poly {
     uint32_t n = 0, n_pad = 0;
     int device = 0;
     smx::PolyArrays d{};               // device arrays
-    int32_t *d_bus = nullptr;          // int32[2*64]
+    int32_t *d_bus2 = nullptr;         // two buses of int32[2*64], used alternately (the fold of block k is done by launch k+1)
+    int32_t *d_bus = nullptr;          // the bus of the last block
+    uint32_t bus_k = 0;
     int32_t *d_slots = nullptr;        // bus copies the workgroups add into (poly_bank.hip), kept zero
+    smx::PolyPending pend;             // the fold the last launch left to its successor
     int32_t *h_bus = nullptr;          // pinned
     hipStream_t stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
@@ -43,7 +46,8 @@ extern "C" smx_poly *smx_poly_create(uint32_t n_voices, int device)
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&p->ev_t0) == hipSuccess && hipEventCreate(&p->ev_t1) == hipSuccess &&
-              hipMalloc((void **)&p->d_bus, 128 * 4) == hipSuccess &&
+              hipMalloc((void **)&p->d_bus2, 2 * smx::poly_bus_bytes()) == hipSuccess &&
+              hipMemsetAsync(p->d_bus2, 0, 2 * smx::poly_bus_bytes(), p->stream) == hipSuccess &&
               hipMalloc((void **)&p->d_slots, smx::poly_scratch_bytes()) == hipSuccess &&
               hipMemsetAsync(p->d_slots, 0, smx::poly_scratch_bytes(), p->stream) == hipSuccess &&
               hipHostMalloc((void **)&p->h_bus, 128 * 4, hipHostMallocDefault) == hipSuccess;
@@ -68,7 +72,7 @@ extern "C" void smx_poly_destroy(smx_poly *p)
     poly_slots(p->d, slots);
     for (int i = 0; i < 12; i++)
         if (*slots[i]) (void)hipFree(*slots[i]);
-    if (p->d_bus) (void)hipFree(p->d_bus);
+    if (p->d_bus2) (void)hipFree(p->d_bus2);
     if (p->d_slots) (void)hipFree(p->d_slots);
     if (p->h_bus) (void)hipHostFree(p->h_bus);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -101,13 +105,20 @@ extern "C" int smx_poly_run_async(smx_poly *p, int n)
 {
     if (!p || n <= 0 || n > 64) { set_error("smx_poly_run_async: n=%d (1..64)", n); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(p->device));
-    return smx::launch_poly_bank(p->d, p->d_bus, p->d_slots, p->n_pad, (uint32_t)n, p->stream);
+    static const bool no_defer = getenv("SMX_POLY_NO_DEFER") != nullptr;      // A/B switch: every launch folds its own copies
+    p->d_bus = p->d_bus2 + (size_t)(p->bus_k++ & 1u) * (smx::poly_bus_bytes() / 4);
+    return smx::launch_poly_bank(p->d, p->d_bus, p->d_slots, p->n_pad, (uint32_t)n, p->stream, no_defer ? nullptr : &p->pend);
 }
+
+// Whoever is about to read the last block's bus first runs the fold its launch deferred (a no-op when nothing is owed).
+static int poly_flush(smx_poly *p) { return smx::launch_poly_flush(&p->pend, p->stream); }
 
 extern "C" int smx_poly_sync(smx_poly *p)
 {
     if (!p) return SMX_E_ARG;
     SMX_HIP(hipSetDevice(p->device));
+    int rv = poly_flush(p);                          // after a sync the last block's bus holds its sums
+    if (rv) return rv;
     SMX_HIP(hipStreamSynchronize(p->stream));
     return SMX_OK;
 }
@@ -118,6 +129,8 @@ extern "C" int smx_poly_run(smx_poly *p, float *vec_lr, int32_t *bus_lr, int n)
     for (int done = 0; done < n;) {
         const int nf = n - done < 64 ? n - done : 64;
         int rv = smx_poly_run_async(p, nf);
+        if (rv) return rv;
+        rv = poly_flush(p);
         if (rv) return rv;
         SMX_HIP(hipMemcpyAsync(p->h_bus, p->d_bus, (size_t)nf * 8, hipMemcpyDeviceToHost, p->stream));
         SMX_HIP(hipStreamSynchronize(p->stream));

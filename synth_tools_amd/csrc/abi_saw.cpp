@@ -3,6 +3,7 @@
 // point needs a HIP device and fails with SMX_E_NOGPU otherwise.
 #include "abi_internal.h"
 #include <rccl/rccl.h>
+#include <time.h>
 #include <unordered_map>
 
 #define SMX_NCCL(expr)                                                         \
@@ -126,6 +127,13 @@ struct smx_bank {
     static constexpr uint32_t RING_MIN_FRAMES = 4096;
     uint32_t scratch_cap = 0;                    // frames d_scratch is sized for
     int32_t *h_bus = nullptr;                    // pinned
+    // The synchronous block's way back to the host (round 3): coherent pinned words that the GPU writes itself --
+    // the block's last (small) kernel publishes the bus and then a sequence number, the host polls that number
+    // instead of queueing a copy and waiting for the stream (saw_publish_kernel / saw_dropin_kernel, saw_bank.hip).
+    static constexpr uint32_t PUB_MAX = 4096;    // frames: longer blocks take the copy
+    int32_t *h_pub = nullptr, *d_pub = nullptr;  // host / device address of the same PUB_MAX words
+    uint32_t *h_pubflag = nullptr, *d_pubflag = nullptr;
+    uint32_t pub_seq = 0;
     // pipelined block mode (smx_bank_set_block_mode): the bus of block k is copied to pinned
     // memory behind its kernel and handed out by the call that launches block k+1
     int block_mode = 0;
@@ -295,6 +303,11 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     if ((e = hipHostMalloc((void **)&b->h_form, 64, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
     b->h_form[0] = 0xFFFFFFFFu;
     b->h_form[1] = 0;
+    if ((e = hipHostMalloc((void **)&b->h_pub, smx_bank::PUB_MAX * 4, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) return fail("hipHostMalloc (coherent)", e);
+    if ((e = hipHostMalloc((void **)&b->h_pubflag, 64, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) return fail("hipHostMalloc (coherent)", e);
+    if ((e = hipHostGetDevicePointer((void **)&b->d_pub, b->h_pub, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
+    if ((e = hipHostGetDevicePointer((void **)&b->d_pubflag, b->h_pubflag, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
+    b->h_pubflag[0] = 0;
     if ((e = hipEventCreate(&b->ev_t0)) != hipSuccess) return fail("event", e);
     if ((e = hipEventCreate(&b->ev_t1)) != hipSuccess) return fail("event", e);
     for (int i = 0; i < smx_bank::NBUS; i++) {
@@ -327,6 +340,8 @@ extern "C" void smx_bank_destroy(smx_bank *b)
     }
     if (b->h_bus) (void)hipHostFree(b->h_bus);
     if (b->h_form) (void)hipHostFree(b->h_form);
+    if (b->h_pub) (void)hipHostFree(b->h_pub);
+    if (b->h_pubflag) (void)hipHostFree(b->h_pubflag);
     for (int i = 0; i < 2; i++) {
         if (b->h_pipe[i]) (void)hipHostFree(b->h_pipe[i]);
         if (b->ev_pipe[i]) (void)hipEventDestroy(b->ev_pipe[i]);
@@ -748,6 +763,62 @@ extern "C" int smx_bank_sync(smx_bank *b)
     return SMX_OK;
 }
 
+// SMX_NO_PUBLISH=1 (A/B switch): the bus comes back by hipMemcpyAsync + hipStreamSynchronize, as before round 3.
+static bool publish_enabled()
+{
+    static const bool on = getenv("SMX_NO_PUBLISH") == nullptr;
+    return on;
+}
+
+// Wait until the GPU has published block `seq` (the flag is written after the bus words, system-scope release).
+// The wait is bounded: a kernel that never arrives (a lost device, a hung queue) must not hold a real-time thread
+// forever -- after SMX_PUBLISH_TIMEOUT_MS (default 10 000) the call fails with SMX_E_NOGPU.
+static int bank_wait_published(smx_bank *b, uint32_t seq)
+{
+    static const double limit_us = [] {
+        const char *e = getenv("SMX_PUBLISH_TIMEOUT_MS");
+        return (e ? atof(e) : 10000.0) * 1e3;
+    }();
+    auto now_us = [] {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+    };
+    double t0 = -1.0;
+    for (uint32_t spins = 1;; spins++) {
+        if (__atomic_load_n(b->h_pubflag, __ATOMIC_ACQUIRE) == seq) return SMX_OK;
+        __builtin_ia32_pause();
+        if ((spins & 0x3FFu) == 0) {                 // look at the clock every 1024 polls
+            const double t = now_us();
+            if (t0 < 0) t0 = t;
+            else if (t - t0 > limit_us) {
+                const hipError_t q = hipStreamQuery(b->stream);
+                set_error("the GPU did not publish block %u within %.0f ms (stream: %s)", seq, limit_us * 1e-3,
+                          q == hipSuccess ? "idle" : hipGetErrorString(q));
+                return SMX_E_NOGPU;
+            }
+        }
+    }
+}
+
+namespace smx {
+// The drop-in synth_run (abi_core.cpp): struct synth's 64 voices for one block, ONE launch, no upload, no copy back
+// (saw_dropin_kernel); longer blocks and SMX_NO_PUBLISH take the bank path (load + run + fetch, one synchronisation).
+int bank_dropin_run(smx_bank *b, const uint32_t *inc, const uint32_t *state, float *vec, int n)
+{
+    if (!b || b->n != 64 || !inc || !state || !vec || n <= 0) { set_error("bank_dropin_run: bad args"); return SMX_E_ARG; }
+    if (!publish_enabled() || n > 1024) return smx_bank_load_run(b, inc, state, vec, nullptr, n);
+    SMX_HIP(hipSetDevice(b->device));
+    const uint32_t seq = ++b->pub_seq;
+    int rv = launch_saw_dropin(inc, state, b->d_pub, b->d_pubflag, (uint32_t)n, seq, b->stream);
+    if (rv) return rv;
+    rv = bank_wait_published(b, seq);
+    if (rv) return rv;
+    for (int i = 0; i < n; i++) vec[i] = bus_to_float(b->h_pub[i]);
+    return SMX_OK;
+}
+}  // namespace smx
+
 extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
 {
     if (!b || n <= 0 || (uint32_t)n > b->bus_cap) { set_error("smx_bank_fetch: bad args"); return SMX_E_ARG; }
@@ -763,10 +834,22 @@ extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
         SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[b->ev_owner[bi]], 0));
         b->comm_pending[bi] = false;
     }
-    SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
-    SMX_HIP(hipStreamSynchronize(b->stream));
-    if (bus) memcpy(bus, b->h_bus, (size_t)n * 4);
-    if (vec) for (int i = 0; i < n; i++) vec[i] = bus_to_float(b->h_bus[i]);
+    const int32_t *src = b->h_bus;
+    if (publish_enabled() && (uint32_t)n <= smx_bank::PUB_MAX) {
+        // the stream's last kernel writes the bus to pinned host memory and then the sequence number: no copy
+        // engine, no completion signal to wait for (22 -> 12 us per synchronous block on small banks)
+        const uint32_t seq = ++b->pub_seq;
+        rv = smx::launch_saw_publish(b->d_bus[bi], b->d_pub, b->d_pubflag, (uint32_t)n, seq, b->stream);
+        if (rv) return rv;
+        rv = bank_wait_published(b, seq);
+        if (rv) return rv;
+        src = b->h_pub;
+    } else {
+        SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+        SMX_HIP(hipStreamSynchronize(b->stream));
+    }
+    if (bus) memcpy(bus, src, (size_t)n * 4);
+    if (vec) for (int i = 0; i < n; i++) vec[i] = bus_to_float(src[i]);
     return SMX_OK;
 }
 
@@ -987,6 +1070,50 @@ extern "C" int smx_bank_set_comm_group(smx_bank *b, int blocks)
         if (rv) return rv;
     }
     b->comm_group = blocks;
+    return SMX_OK;
+}
+
+// Measurement aid (no reference counterpart): what ONE bus sum of n_words int32 costs on this communicator, with no
+// kernel in between -- the L of DESIGN 4's latency budget, measured instead of assumed.  Collective: every rank calls
+// it with the same arguments.  us_sync: host time per all-reduce when each one is waited for (launch + collective +
+// hipStreamSynchronize: what a synchronous smx_bank_run pays on top of its kernel); us_queued: per all-reduce when
+// `reps` of them are queued back to back and waited for once (the comm stream's own rate: what throughput mode
+// has to hide behind a group of kernels).
+extern "C" int smx_bank_comm_probe(smx_bank *b, uint32_t n_words, uint32_t reps, float *us_sync, float *us_queued)
+{
+    if (!b || n_words == 0 || n_words > (1u << 20) || reps == 0 || reps > 100000u) {
+        set_error("smx_bank_comm_probe: n_words=%u (1..2^20) reps=%u (1..100000)", n_words, reps);
+        return SMX_E_ARG;
+    }
+    if (!b->comm) { set_error("smx_bank_comm_probe: smx_bank_comm_init not called"); return SMX_E_STATE; }
+    SMX_HIP(hipSetDevice(b->device));
+    int rv = smx_bank_sync(b);                      // issues what is queued; both streams idle
+    if (rv) return rv;
+    struct Scratch {
+        int32_t *d = nullptr;
+        ~Scratch() { if (d) (void)hipFree(d); }
+    } sc;
+    SMX_HIP(hipMalloc((void **)&sc.d, (size_t)n_words * 4));
+    SMX_HIP(hipMemsetAsync(sc.d, 0, (size_t)n_words * 4, b->comm_stream));
+    auto now_us = [] {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+    };
+    for (int k = 0; k < 3; k++)                     // warm-up: the first collectives of a size set up their channels
+        SMX_NCCL(ncclAllReduce(sc.d, sc.d, n_words, ncclInt32, ncclSum, b->comm, b->comm_stream));
+    SMX_HIP(hipStreamSynchronize(b->comm_stream));
+    double t0 = now_us();
+    for (uint32_t k = 0; k < reps; k++) {
+        SMX_NCCL(ncclAllReduce(sc.d, sc.d, n_words, ncclInt32, ncclSum, b->comm, b->comm_stream));
+        SMX_HIP(hipStreamSynchronize(b->comm_stream));
+    }
+    if (us_sync) *us_sync = (float)((now_us() - t0) / reps);
+    t0 = now_us();
+    for (uint32_t k = 0; k < reps; k++)
+        SMX_NCCL(ncclAllReduce(sc.d, sc.d, n_words, ncclInt32, ncclSum, b->comm, b->comm_stream));
+    SMX_HIP(hipStreamSynchronize(b->comm_stream));
+    if (us_queued) *us_queued = (float)((now_us() - t0) / reps);
     return SMX_OK;
 }
 

@@ -1026,6 +1026,46 @@ void saw_materialize_kernel(const uint32_t *__restrict__ inc, uint32_t *__restri
         state0[v] += tbase * inc[v];
 }
 
+// Publish a finished bus to the host WITHOUT a copy engine and without hipStreamSynchronize (round 3): one small
+// workgroup at the end of the block's work on the stream writes the n sums to coherent pinned host memory, makes them
+// visible system-wide and then writes the block's sequence number; the host polls that word (abi_saw.cpp).  Measured
+// (tools/ubench/sync_latency.hip): launch + 256-byte hipMemcpyAsync + hipStreamSynchronize 15.2 us, launch + this
+// kernel + poll 11.1 us, a producing kernel that publishes by itself 8.1 us.
+__global__ __launch_bounds__(256)
+void saw_publish_kernel(const int32_t *__restrict__ bus, int32_t *__restrict__ hbus, uint32_t *__restrict__ hflag,
+                        uint32_t n, uint32_t seq)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) __builtin_nontemporal_store(bus[i], &hbus[i]);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(hflag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The reference's own operating point -- struct synth's 64 voices, one process() block (linux/synth.c:169-202,
+// 261-276) -- as ONE launch: the 64 {inc, state} pairs travel as kernel arguments (512 bytes: no upload), they are
+// wave-uniform and live in scalar registers, one lane per FRAME sums (int)(state + t*inc) >> 4 over the voices
+// that are on (the phasor is linear, so frame t needs no frame t-1), and the kernel publishes the bus to pinned
+// host memory itself (see saw_publish_kernel).  Blocks of up to 1024 frames; one workgroup.
+struct DropinVoices { uint32_t inc[64], state[64]; };
+__global__ __launch_bounds__(1024)
+void saw_dropin_kernel(DropinVoices a, int32_t *__restrict__ hbus, uint32_t *__restrict__ hflag, uint32_t n, uint32_t seq)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < n) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int v = 0; v < 64; v++) {
+            const uint32_t inc = a.inc[v];                                   // scalar: the same voice for every lane
+            const int32_t ph = (int32_t)(a.state[v] + t * inc);
+            sum += inc ? (uint32_t)(ph >> 4) : 0u;                           // inc == 0: the voice is off
+        }
+        __builtin_nontemporal_store((int32_t)sum, &hbus[t]);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(hflag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Grid: persistent workgroups, grid-stride over voices.  Two effects set the size:
 //  * every workgroup ends with one integer atomic per frame on the same bus words, and those
 //    serialise (~20 ns each): a 1 Mi-voice block of 64 frames takes 12.6 us with 256
@@ -1342,6 +1382,25 @@ int launch_saw_sum_inc(const uint32_t *d_inc, uint32_t n_pad, void *d_scratch, h
     uint32_t gx = n_pad / 1024;
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(saw_sum_inc_kernel, dim3(gx), dim3(256), 0, stream, d_inc, n_pad, static_cast<uint32_t *>(d_scratch));
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_saw_publish(const int32_t *d_bus, int32_t *d_hbus, uint32_t *d_hflag, uint32_t n, uint32_t seq, hipStream_t stream)
+{
+    hipLaunchKernelGGL(saw_publish_kernel, dim3(1), dim3(256), 0, stream, d_bus, d_hbus, d_hflag, n, seq);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_saw_dropin(const uint32_t inc[64], const uint32_t state[64], int32_t *d_hbus, uint32_t *d_hflag, uint32_t n,
+                      uint32_t seq, hipStream_t stream)
+{
+    if (n == 0 || n > 1024) { set_error("launch_saw_dropin: n=%u (1..1024)", n); return SMX_E_ARG; }
+    DropinVoices a;
+    memcpy(a.inc, inc, sizeof(a.inc));
+    memcpy(a.state, state, sizeof(a.state));
+    hipLaunchKernelGGL(saw_dropin_kernel, dim3(1), dim3((n + 63u) & ~63u), 0, stream, a, d_hbus, d_hflag, n, seq);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

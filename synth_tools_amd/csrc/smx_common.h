@@ -59,6 +59,13 @@ struct SawPending {
 };
 size_t saw_scratch_region_bytes(uint32_t max_frames);
 int launch_saw_flush(SawPending *pend, hipStream_t stream);
+// d_hbus / d_hflag: DEVICE pointers of coherent pinned host memory.  The kernel writes n bus words there, then seq to
+// *d_hflag (system-scope release): the host polls the flag instead of waiting for a copy and a stream.
+int launch_saw_publish(const int32_t *d_bus, int32_t *d_hbus, uint32_t *d_hflag, uint32_t n, uint32_t seq, hipStream_t stream);
+// struct synth's 64 voices (linux/synth.c:31-40) for one block of n <= 1024 frames in ONE launch: the voices are kernel
+// arguments, the bus goes straight to pinned host memory (published as above).  Nothing in HBM is read or written.
+int launch_saw_dropin(const uint32_t inc[64], const uint32_t state[64], int32_t *d_hbus, uint32_t *d_hflag, uint32_t n,
+                      uint32_t seq, hipStream_t stream);
 // long_block_form: SMX_FORM_AUTO / SMX_FORM_STEPPING / SMX_FORM_EVENTS (include/synth_mi355x.h)
 // host_flag: two pinned (device-visible) words that receive, after every long block, the form the device
 // would pick next (0 stepping, 1 events) and host_tag, the caller's own number of this block; or NULL.
@@ -96,11 +103,22 @@ struct PolyArrays {
     float *y, *a;
     uint32_t *level, *stage, *gate, *ar, *dr, *sl, *rr, *pan;
 };
-// d_slots: poly_scratch_bytes() of zeroed device memory (left zeroed again by every launch);
-// d_bus_lr[0 .. 2*nframes) is overwritten, not accumulated into.
+// The fold a launch left to its successor (poly_bank.hip): the copies it filled and the bus they belong to.
+struct PolyPending {
+    int32_t *slots = nullptr;           // nullptr: nothing owed
+    int32_t *bus = nullptr;
+    uint32_t region = 0;                // which of the two regions of copies the NEXT launch fills
+};
+// d_slots: poly_scratch_bytes() of zeroed device memory = two regions of copies (kept zero between uses);
+// d_bus_lr: poly_bus_bytes(); rows [0, 2*nframes) receive the block's stereo sums.
+// pend == nullptr: the launch folds its own copies (a second kernel) and d_bus_lr is complete when it has run.
+// pend != nullptr: the fold is deferred -- the next launch_poly_bank with the same pend does it (pass the OTHER bus
+// buffer there), or launch_poly_flush.
 size_t poly_scratch_bytes();
+size_t poly_bus_bytes();
+int launch_poly_flush(PolyPending *pend, hipStream_t stream);
 int launch_poly_bank(const PolyArrays &p, int32_t *d_bus_lr, int32_t *d_slots, uint32_t n_pad,
-                     uint32_t nframes, hipStream_t stream);
+                     uint32_t nframes, hipStream_t stream, PolyPending *pend = nullptr);
 
 // Noise-shaped PWM bank (pwm_bank.hip): device SoA arrays, n_pad entries each.
 struct PwmArrays {

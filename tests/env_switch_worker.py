@@ -7,6 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
@@ -34,6 +35,37 @@ def main():
                 checks += 1
         assert np.array_equal(bank.read()[1], st), (n, "phases")
         bank.close()
+    # the drop-in synth_run on a caller-owned struct synth (one launch that publishes its own bus; SMX_NO_PUBLISH:
+    # upload + bank kernel + copy), against the REFERENCE's committed outputs: 1-, 64-, 256- and 4096-frame blocks
+    import replay
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "synth_c_reference.npz"))
+    for name in ("b1_ticks", "b64_quirks", "b4096_random", "wrapping_mix"):
+        vec, n2v, inc, st = replay.on_struct_synth(sta.lib(), sta.Synth, gold[name + "_script"], square=sta.lib().sum_tick_square)
+        assert np.array_equal(vec, gold[name + "_vec_bits"]), name
+        assert np.array_equal(st, gold[name + "_state"]) and np.array_equal(inc, gold[name + "_inc"]), name
+        checks += 1
+    # the poly bank: un-fetched blocks, then a fetched one (the fold deferred to the next launch; SMX_POLY_NO_DEFER:
+    # every launch folds its own copies)
+    import ctypes as C
+    n = 5000
+    a = synthetic.poly_bank(n, 0x5EED0E04, tab, active_fraction=0.9)
+    pb = sta.PolyBank(n)
+    pb.load(**a)
+    ob = oracle.PolyBank(n=n, **{k: v.ctypes.data for k, v in a.items()})
+    for k, nf in enumerate((64, 64, 7, 64, 1, 64)):
+        want = np.zeros(2 * nf, np.int32)
+        orc.orc_poly_run(C.byref(ob), want, nf)
+        if k in (2, 3, 5):
+            got, _ = pb.run(nf)
+            assert np.array_equal(got.reshape(-1), want), ("poly", k, nf)
+            checks += 1
+        else:
+            pb.run_async(nf)
+    got = pb.read()
+    for f in ("phase", "level", "stage"):
+        assert np.array_equal(got[f], a[f]), ("poly state", f)
+    assert np.array_equal(got["y"].view(np.uint32), a["y"].view(np.uint32))
+    pb.close()
     print("ok", checks)
 
 

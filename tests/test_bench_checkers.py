@@ -65,6 +65,31 @@ def test_poly_block_numpy_equals_oracle(orc):
         assert np.array_equal(want_np, bus.reshape(64, 2).astype(np.int64)), blk
 
 
+def test_pwm2_block_numpy_equals_oracle(orc):
+    """bench.py's PWM leg check: the numpy statement of the firmware's order-2 channel against orc_pwm_bank_run
+    (whose shaper is pinned by the real pdm.h), across control-rate boundaries."""
+    n = 700
+    r = synthetic.splitmix64(0x5EED0B08, 7 * n).reshape(7, n)
+    st = {k: (r[i] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+          for i, k in enumerate(("setpoint", "pos0", "vel0", "pos1", "vel1", "s1", "s2"))}
+    st["vel0"] = (st["vel0"] >> np.uint32(12)).astype(np.uint32)
+    st["vel1"] = (0 - (st["vel1"] >> np.uint32(13))).astype(np.uint32)          # negative velocities too
+    for div_log, div_count, nt in ((12, 4096 - 100, 256), (4, 3, 100), (12, 0, 5)):
+        o = {k: v.copy() for k, v in st.items()}
+        b = oracle.PwmBank(n=n, setpoint=o["setpoint"].ctypes.data, pos0=o["pos0"].ctypes.data, vel0=o["vel0"].ctypes.data,
+                           pos1=o["pos1"].ctypes.data, vel1=o["vel1"].ctypes.data,
+                           s=(C.c_void_p * 4)(o["s1"].ctypes.data, o["s2"].ctypes.data, None, None), order=2,
+                           div_count=div_count, div_log=div_log, out_shift=24)
+        dith = synthetic.dither_stream(nt, 11, 0x3FF)
+        want = np.zeros((nt, n), np.uint8)
+        orc.orc_pwm_bank_run(C.byref(b), dith.ctypes.data, nt, want.ctypes.data)
+        got, after = bench.pwm2_block_numpy(st, dith, nt, div_count, div_log=div_log)
+        assert np.array_equal(got, want), (div_log, div_count)
+        for k in o:
+            assert np.array_equal(after[k], o[k]), (k, div_log, div_count)
+        st = after
+
+
 def test_roof_and_wrap_helpers():
     assert bench.wrap_i32([2**31, -2**31 - 1, 5]).tolist() == [-2**31, 2**31 - 1, 5]
     r = bench.roof(8e9, 1.0)                                    # 8 GB in 1 ms = 8 TB/s

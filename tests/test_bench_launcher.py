@@ -47,6 +47,17 @@ def test_rendezvous_world_4_with_an_explicit_directory(tmp_path):
     assert not os.path.exists(tmp_path / "rdzv" / "port")          # rank 0 removed it
 
 
+def test_rendezvous_world_8(tmp_path):
+    """The driver's 8-GPU leg: eight ranks through the id broadcast, 50 barriers, the max over ranks and the
+    all-gather the per-rank kernel times travel in (bench.py gather_floats).  (Eight GPU processes cannot be rehearsed
+    on the one-GPU box: its process guard admits six.)"""
+    res = _spawn(8, {"SMX_RDZV_DIR": str(tmp_path / "rdzv8")})
+    assert len(res) == 8
+    for rc, out, err in res:
+        assert rc == 0, err
+        assert '"ok": true' in out
+
+
 def test_rendezvous_directory_derived_like_under_torchrun():
     """No SMX_RDZV_DIR: the directory comes from MASTER_PORT and the common parent pid (what the workers
     of `python -m torch.distributed.run` share); torchrun's own store keeps MASTER_PORT itself."""

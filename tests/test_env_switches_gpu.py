@@ -8,7 +8,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-SWITCHES = ["", "SMX_SAW_NO_WIDE", "SMX_SAW_NO_DEFER", "SMX_SAW_NO_SLOTS", "SMX_SAW_NO_CARRY", "SMX_SAW_NO_LONG_EVENTS"]
+SWITCHES = ["", "SMX_SAW_NO_WIDE", "SMX_SAW_NO_DEFER", "SMX_SAW_NO_SLOTS", "SMX_SAW_NO_CARRY", "SMX_SAW_NO_LONG_EVENTS", "SMX_NO_PUBLISH",
+            "SMX_POLY_NO_DEFER"]
 
 
 @pytest.mark.parametrize("switch", SWITCHES)

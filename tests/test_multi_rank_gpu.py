@@ -104,8 +104,8 @@ def test_bench_with_two_ranks_on_the_one_gpu(smx):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(LD_PRELOAD=fake, SMX_BENCH_DEVICES="0,0")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--voices", str(1 << 20),
-                        "--frames", "64", "--steps", "40", "--warmup", "5"], env=env, capture_output=True, text=True,
-                       timeout=300)
+                        "--frames", "64", "--steps", "40", "--warmup", "5", "--repeats", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
@@ -113,6 +113,45 @@ def test_bench_with_two_ranks_on_the_one_gpu(smx):
     assert line["config"]["voices_total"] == 2 << 20
     # 45 blocks + the checked one; one collective per 8 blocks (+ the ring's wrap and the final flushes)
     assert line["collectives"]["block_sums_carried"] == 46 and line["collectives"]["issued"] <= 10
+
+
+def test_bench_config5_legs_with_five_ranks_on_the_one_gpu(smx):
+    """The line the one hardware shot at N > 1 will print, rehearsed with as many ranks as this box allows: the pool's
+    process guard admits 6 processes on the card at once and this pytest process is one of them, so FIVE ranks share
+    the GPU through the RCCL test double (the 8-rank rendezvous and launcher run on the CPU in
+    tests/test_bench_launcher.py; the double itself takes up to 8).  `also` must carry BASELINE config 5 as written
+    (1 Mi voices per GPU) at 1 and 64 frames with 1 / 8 / 16 blocks per collective, the synchronous and the
+    pipelined smx_bank_run, each with its bus check summed over the ranks, and the collective-only probe."""
+    fake = _fake_rccl()
+    if fake is None:
+        pytest.skip("hipcc not available to build the RCCL test double")
+    root = os.path.dirname(HERE)
+    world = 5
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(LD_PRELOAD=fake, SMX_BENCH_DEVICES=",".join(["0"] * world))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--voices", str(1 << 20),
+                        "--steps", "40", "--warmup", "5", "--repeats", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["ranks_seen"] == world and line["repeats"] == 3
+    assert line["ms_per_step_min"] <= line["ms_per_step"] <= line["ms_per_step_max"]
+    assert "summed over %d ranks" % world in line["verified"]
+    also = line["also"]
+    thr = [e for e in also if "throughput mode" in e["workload"]]
+    assert sorted((e["roofline"]["algorithmic_bytes"], e["comm_group"]) for e in thr) == \
+        sorted((8.0 * (1 << 20) + 4.0 * f, g) for f in (1, 64) for g in (1, 8, 16))
+    for e in thr:
+        assert e["n_gpus"] == world and e["verified"] and e["kernel_ms_per_rank"]["min"] <= e["kernel_ms_per_rank"]["max"]
+        steps = 400 if "1 frame(s)" in e["workload"] else 200
+        assert e["block_sums_carried"] == steps
+        # one collective per `group` blocks, plus the ring's wrap closing a group early and the final flush
+        assert steps // e["comm_group"] <= e["collectives_issued"] <= steps // e["comm_group"] + steps // 32 + 2
+    runs = [e for e in also if "smx_bank_run" in e["workload"]]
+    assert len(runs) == 4 and all(e["us_per_block"] > 0 and e["verified"] for e in runs)
+    sizes = line["collective_probe"]["sizes"]
+    assert [s["bytes"] for s in sizes] == [256, 2048, 32768]
+    assert all(s["collective_us"] > 0 and s["collective_us_queued"] > 0 for s in sizes)
+    assert line["roofline"]["kernel_ms_per_rank"]["max"] >= line["roofline"]["kernel_ms_per_rank"]["min"] > 0
 
 
 def test_the_test_double_catches_a_broken_spmd_contract(smx):
@@ -162,7 +201,7 @@ def test_global_allocator_over_sharded_banks(smx, world, voices):
             assert r["bank_filled_up"]                       # so the steal-voice-0 path ran
 
 
-@pytest.mark.parametrize("ranks,fill,pipeline", [(2, False, False), (4, True, False), (2, True, True)])
+@pytest.mark.parametrize("ranks,fill,pipeline", [(2, False, False), (4, True, False), (2, True, True), (5, True, True)])
 def test_jack_host_program_over_several_ranks(smx, orc, tmp_path, ranks, fill, pipeline):
     """host/synth.dynamic.host.elf with SYNTH_RANKS: the one JACK client (fake JACK here) forks helper ranks before
     any GPU call, forwards every block's MIDI events and frame count over pipes, each rank runs its shard of the
