@@ -235,6 +235,37 @@ def roof(alg_bytes, ms, units=None, issue_cycles=None):
     return r
 
 
+_COUNTERS = None
+
+
+def recorded_issue(kernel_has, ms, cycles_per_inst):
+    """`valu_issue_frac` for a kernel whose loop has no closed instruction count (data-dependent trip counts, or a mix
+    of integer / fp32 / LDS work): the vector instructions per launch RECORDED by tools/prof_counters.sh
+    (profiles/counters.json: SQ_INSTS_VALU of one rocprofv3 --pmc pass over this bench) x the mean issue cost of the
+    loop's instruction mix (profiles/r02_valu_rates.txt), against the launch time measured now.  -> (fraction, note)
+    or (None, None) when the kernel is not in the record."""
+    global _COUNTERS
+    if _COUNTERS is None:
+        path = os.path.join(ROOT, "profiles", "counters.json")
+        _COUNTERS = json.load(open(path)) if os.path.exists(path) else {}
+    for name, c in _COUNTERS.get("kernels", {}).items():
+        if all(k in name for k in kernel_has) and c.get("SQ_INSTS_VALU"):
+            frac = c["SQ_INSTS_VALU"] / 1024.0 * cycles_per_inst / (2.4e9 * ms * 1e-3)
+            return round(frac, 4), ("recorded: %s -- %.0f vector instructions per launch x %.2f SIMD cycles each (mean of the "
+                                    "loop's mix, profiles/r02_valu_rates.txt), not measured in this run"
+                                    % (_COUNTERS.get("source", "profiles/counters.json"), c["SQ_INSTS_VALU"], cycles_per_inst))
+    return None, None
+
+
+def with_recorded_issue(e, kernel_has, cycles_per_inst):
+    frac, note = recorded_issue(kernel_has, e["ms_per_step"], cycles_per_inst)
+    if frac is not None:
+        e["roofline"]["valu_issue_frac"] = frac
+        e["roofline"]["valu_issue_source"] = note
+        e["roofline"]["bound"] = "vector issue" if frac > e["roofline"]["hbm_frac"] else "hbm"
+    return e
+
+
 def saw_roofline(voices, frames, kernel_ms):
     # 8 B read per voice (inc + state0; the advanced phase is never written back: DESIGN.md 2)
     alg_bytes = 8.0 * voices + 4.0 * frames
@@ -449,6 +480,10 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
                     voices, frames, ms, valu,
                     {"formulation": ("carry, wrap events (AUTO: picked on the device from the bank's increments)" if events
                                      else "carry, stepping") if carry else "direct"}))
+                if events:
+                    # divisions, compares, selects, multiplies: mostly the 4.3-4.7-cycle class, some 2.7-cycle adds
+                    with_recorded_issue(out[-1], ("saw_bank_event_long_kernel", "1024u") if frames >= 1024
+                                        else ("saw_bank_carry_kernel", "64, true"), 4.0)
         big.bank.set_block_form(SMX_FORM_AUTO)
     if "saw_hi" in legs:
         # the same 64-frame blocks on a bank of high voices only (MIDI notes 100..127: 3..17 wraps per voice per
@@ -619,11 +654,10 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
         checked = None
         if verify:
             # a block in the middle of the attacks and decays (20 blocks after the gates went on) and one of the settled bank
-            for what, gate, blocks in (("envelopes moving", on, 20), ("settled", arrs["gate"], 0)):
-                if blocks:
-                    pb.load(**dict(arrs, gate=gate))
-                    for _ in range(blocks):
-                        pb.run_async(64)
+            for what, gate, blocks in (("envelopes moving", on, 20), ("settled", arrs["gate"], 400)):
+                pb.load(**dict(arrs, gate=gate))
+                for _ in range(blocks):
+                    pb.run_async(64)
                 cur = pb.read()
                 cur["gate"] = gate
                 want = poly_block_numpy(cur, 64)
@@ -637,8 +671,12 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
             e = {"workload": "c4: poly bank (saw+LPF+ADSR, stereo; build-defined), %d voices, 64 frames/step, %s" % (n, what),
                  "value": round(n * 64 / (t * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(t, 5),
                  "roofline": roof(60.0 * n + 64 * 8, t, n * 64, ISSUE["poly"]), "verified": checked}
-            e["roofline"]["bound"] = "vector issue at 4 waves per SIMD (256 Ki voices = 16 waves per CU) + launch floor; profiles/"
             e["hbm_frac"] = e["roofline"]["hbm_frac"]
+            # 14 (down-only envelope) .. 16 (general) instructions per voice-sample, mean 2.9-3.05 cycles each
+            with_recorded_issue(e, ("poly_bank_kernel",), 3.0)
+            e["roofline"]["bound"] = ("vector issue + LDS atomics, NOT overlapped at 4 waves per SIMD (256 Ki voices = 16 waves per CU: "
+                                      "32 ds_add x 4.2 cycles + 4 x 14..16 vector instructions x ~3 cycles per frame and CU, "
+                                      "profiles/r03_lds_rates.txt), on top of a 4.4 us one-frame launch")
             out.append(e)
     return out
 

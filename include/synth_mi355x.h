@@ -372,6 +372,27 @@ int smx_clock_read(smx_clock *c, uint32_t *hperiod, int32_t *phase, uint32_t *po
  * frame-major, clock c in bit c&31 of word c>>5; either may be NULL. */
 int smx_clock_run(smx_clock *c, uint32_t n_frames, uint32_t *pol_bits, uint32_t *tick_bits);
 
+/* ---- 6b. mod_pdm.c as ONE module: its timer ISR HW_TIM_ISR(TIM_PDM) (stm32f103/mod_pdm.c:177-194) runs, per tick,
+ * pdm_update() (the carry-out channels), val = pwm_update() (the fixed-rate PWM channel, mod_pdm.c:166-175, hard-synced
+ * by the oscillator ISR, mod_osc.c:60-62) and, every CONTROL_DIV = 256 ticks (mod_pdm.c:164-165, 184-192),
+ * control_trigger().  smx_modpdm is a PDM bank of n_channels and an oscillator bank of n_osc ticking in lockstep
+ * (one kernel each, side by side) plus that divider; the banks are created in the firmware's initial state (pdm_init:
+ * mod_pdm.c:320-326; pwm_phase 0, pwm_speed 256*13) and are reached through the borrowed handles for
+ * smx_pdm_load / _read / _set_setpoint and smx_osc_load_pwm / _read_pwm.  control_trigger() pends control_update
+ * (mod_controlrate.c:52-55), whose beat divider is reported like smx_pwm_controlrate's. */
+typedef struct smx_modpdm smx_modpdm;
+smx_modpdm *smx_modpdm_create(uint32_t n_channels, uint32_t n_osc, int device);
+void        smx_modpdm_destroy(smx_modpdm *m);
+smx_pdm    *smx_modpdm_pdm(smx_modpdm *m);          /* borrowed handles */
+smx_osc    *smx_modpdm_osc(smx_modpdm *m);
+/* n_ticks of the ISR.  dither: host uint32[n_ticks] or NULL (as smx_pdm_tick_n); sync_bits: OSC_HARD_SYNC bit matrix
+ * or NULL (as smx_osc_tick_n); bits: host uint32[n_ticks][ceil(n_channels/32)] or NULL; duty: host
+ * uint8[n_ticks][n_osc] or NULL; *control_triggers: control_trigger() calls of this run. */
+int smx_modpdm_tick_n(smx_modpdm *m, uint32_t n_ticks, const uint32_t *dither, const uint32_t *sync_bits,
+                      uint32_t *bits, uint8_t *duty, uint32_t *control_triggers);
+uint32_t smx_modpdm_control_div_count(const smx_modpdm *m);
+int smx_modpdm_controlrate(const smx_modpdm *m, uint32_t *isr_count, uint32_t *beat_pulse, uint32_t *beat_handled);
+
 /* ======================================================================== */
 /* 7. Firmware control surface, hosted: stm32f103/mod_synth.c:50-137 and the   */
 /*    packet entry stm32f103/synth.c:27-42                                     */

@@ -170,6 +170,13 @@ ABI = [
     ("smx_clock_load", C.c_int, [_P, _P, _P, _P]),
     ("smx_clock_read", C.c_int, [_P, _P, _P, _P]),
     ("smx_clock_run", C.c_int, [_P, C.c_uint32, _P, _P]),
+    ("smx_modpdm_create", _P, [C.c_uint32, C.c_uint32, C.c_int]),
+    ("smx_modpdm_destroy", None, [_P]),
+    ("smx_modpdm_pdm", _P, [_P]),
+    ("smx_modpdm_osc", _P, [_P]),
+    ("smx_modpdm_tick_n", C.c_int, [_P, C.c_uint32, _P, _P, _P, _P, C.POINTER(C.c_uint32)]),
+    ("smx_modpdm_control_div_count", C.c_uint32, [_P]),
+    ("smx_modpdm_controlrate", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("smx_cproc_create", _P, [C.c_uint32, C.POINTER(CprocNode), C.c_uint32, C.c_uint32, C.c_int]),
     ("smx_cproc_destroy", None, [_P]),
     ("smx_cproc_tick_n", C.c_int, [_P, C.c_uint32, _P, _P, C.c_uint32, _P]),
@@ -612,6 +619,50 @@ class OscBank:
 
 
 PATCH_BAD_REF, PATCH_BAD_NODE, PATCH_ALLOC_FAIL = -11, -12, -13
+
+
+class ModPdm:
+    """mod_pdm.c as one module (its timer ISR, stm32f103/mod_pdm.c:177-194): a PDM bank and an oscillator bank ticking
+    in lockstep plus the control-rate divider.  `pdm` / `osc` are views of the module's own banks (borrowed handles)."""
+
+    def __init__(self, n_channels, n_osc=1, device=0):
+        self._h = lib().smx_modpdm_create(n_channels, n_osc, device)
+        if not self._h:
+            raise SmxError("smx_modpdm_create: " + lib().smx_last_error().decode())
+        self.pdm = PdmBank.__new__(PdmBank)
+        self.pdm._h, self.pdm.n, self.pdm.words = lib().smx_modpdm_pdm(self._h), n_channels, (n_channels + 31) // 32
+        self.pdm.close = lambda: None                      # the module owns it
+        self.osc = OscBank.__new__(OscBank)
+        self.osc._h, self.osc.n, self.osc.words = lib().smx_modpdm_osc(self._h), n_osc, (n_osc + 31) // 32
+        self.osc.close = lambda: None
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            self.pdm._h = self.osc._h = None
+            _lib.smx_modpdm_destroy(self._h)
+        self._h = None
+
+    __del__ = close
+
+    def tick_n(self, n_ticks, dither=None, sync_bits=None):
+        """-> (pulse bits uint32[n_ticks, words], duty uint8[n_ticks, n_osc], control_trigger() calls)"""
+        d = None if dither is None else np.ascontiguousarray(dither, np.uint32)
+        sb = None if sync_bits is None else np.ascontiguousarray(sync_bits, np.uint32)
+        bits = np.empty((n_ticks, self.pdm.words), np.uint32)
+        duty = np.empty((n_ticks, self.osc.n), np.uint8)
+        trig = C.c_uint32()
+        _check(lib().smx_modpdm_tick_n(self._h, n_ticks, _ptr(d), _ptr(sb), _ptr(bits), _ptr(duty), C.byref(trig)),
+               "smx_modpdm_tick_n")
+        return bits, duty, trig.value
+
+    @property
+    def control_div_count(self):
+        return lib().smx_modpdm_control_div_count(self._h)
+
+    def controlrate(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().smx_modpdm_controlrate(self._h, C.byref(a), C.byref(b), C.byref(c)), "smx_modpdm_controlrate")
+        return a.value, b.value, c.value
 
 
 class Patch:

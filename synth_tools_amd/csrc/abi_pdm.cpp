@@ -230,3 +230,95 @@ extern "C" uint32_t smx_pdm_bsrr_word(uint32_t pulse_bits, uint32_t nb)
     return set | (clr << 16);
 }
 
+
+// ---------------------------------------------------------------------------
+// mod_pdm.c as ONE module: its timer ISR (stm32f103/mod_pdm.c:177-194) does, per tick,
+//     pdm_update();                      the carry-out channels' pulses          (:259-286)
+//     val = pwm_update();                the fixed-rate PWM channel's duty       (:166-175; hard sync: mod_osc.c:60-62)
+//     if (control_div_count == 0) control_trigger();
+//     control_div_count = (control_div_count + 1) % CONTROL_DIV;                 (CONTROL_DIV 256, :164)
+// Here: a PDM bank and an oscillator bank ticking in lockstep (their kernels run side by side on the two banks'
+// streams: the channels and the oscillators share no state) and the divider on the host.  control_trigger() pends
+// the software interrupt whose handler is control_update (mod_controlrate.c:52-55): its beat divider
+// (`if (isr_count % 1024 == 0) beat_pulse++; isr_count++`) is kept per module like smx_pwm_controlrate's.
+// ---------------------------------------------------------------------------
+struct smx_modpdm {
+    smx_pdm *pdm = nullptr;
+    smx_osc *osc = nullptr;
+    uint32_t control_div_count = 0;                 // mod_pdm.c:165
+    uint32_t isr_count = 0, beat_pulse = 0, beat_handled = 0;   // struct controlrate, mod_controlrate.c:21-26
+};
+static constexpr uint32_t MODPDM_CONTROL_DIV = 256;                 // mod_pdm.c:164
+
+extern "C" smx_modpdm *smx_modpdm_create(uint32_t n_channels, uint32_t n_osc, int device)
+{
+    if (n_osc == 0) { set_error("smx_modpdm_create: n_osc=0 (the module has a PWM channel)"); return nullptr; }
+    smx_modpdm *m = new smx_modpdm();
+    m->pdm = smx_pdm_create(n_channels, device);
+    m->osc = m->pdm ? smx_osc_create(n_osc, device) : nullptr;      // pwm_phase 0, pwm_speed 256 * 13 (mod_pdm.c:160-161)
+    if (!m->pdm || !m->osc || smx_pdm_init(m->pdm) != SMX_OK) {     // pdm_init: setpoints (mod_pdm.c:320-326)
+        smx_modpdm_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+extern "C" void smx_modpdm_destroy(smx_modpdm *m)
+{
+    if (!m) return;
+    smx_pdm_destroy(m->pdm);
+    smx_osc_destroy(m->osc);
+    delete m;
+}
+
+extern "C" smx_pdm *smx_modpdm_pdm(smx_modpdm *m) { return m ? m->pdm : nullptr; }
+extern "C" smx_osc *smx_modpdm_osc(smx_modpdm *m) { return m ? m->osc : nullptr; }
+extern "C" uint32_t smx_modpdm_control_div_count(const smx_modpdm *m) { return m ? m->control_div_count : 0; }
+
+extern "C" int smx_modpdm_controlrate(const smx_modpdm *m, uint32_t *isr_count, uint32_t *beat_pulse, uint32_t *beat_handled)
+{
+    if (!m) return SMX_E_ARG;
+    if (isr_count) *isr_count = m->isr_count;
+    if (beat_pulse) *beat_pulse = m->beat_pulse;
+    if (beat_handled) *beat_handled = m->beat_handled;
+    return SMX_OK;
+}
+
+// n_ticks of the ISR.  bits: host uint32[n_ticks][ceil(n_channels/32)] or NULL; duty: host uint8[n_ticks][n_osc] or
+// NULL; dither / sync_bits as smx_pdm_tick_n / smx_osc_tick_n (NULL: none).  *control_triggers receives the number
+// of control_trigger() calls of this run (ticks that began with control_div_count == 0).
+extern "C" int smx_modpdm_tick_n(smx_modpdm *m, uint32_t n_ticks, const uint32_t *dither, const uint32_t *sync_bits,
+                                 uint32_t *bits, uint8_t *duty, uint32_t *control_triggers)
+{
+    if (!m) return SMX_E_ARG;
+    if (control_triggers) *control_triggers = 0;
+    if (n_ticks == 0) return SMX_OK;
+    smx_pdm *p = m->pdm;
+    SMX_HIP(hipSetDevice(p->device));
+    int rv = pdm_ensure(p, n_ticks);
+    if (rv) return rv;
+    // the channels' kernel is queued on the PDM bank's stream ...
+    if (dither)
+        SMX_HIP(hipMemcpyAsync(p->d_dither, dither, (size_t)n_ticks * 4, hipMemcpyHostToDevice, p->stream));
+    rv = smx_pdm_tick_n_async(p, n_ticks, dither != nullptr);
+    if (rv) return rv;
+    if (bits) {
+        const size_t words = (p->n + 31) / 32;
+        SMX_HIP(hipMemcpy2DAsync(bits, words * 4, p->d_bits, (size_t)p->n_pad / 8, words * 4, n_ticks,
+                                 hipMemcpyDeviceToHost, p->stream));
+    }
+    // ... and runs beside the oscillators' (their own stream; this call waits for that one)
+    rv = smx_osc_tick_n(m->osc, n_ticks, sync_bits, duty);
+    if (rv) return rv;
+    SMX_HIP(hipStreamSynchronize(p->stream));
+    // the divider: ticks t of this run with (control_div_count + t) % CONTROL_DIV == 0
+    const uint32_t first = (MODPDM_CONTROL_DIV - m->control_div_count) % MODPDM_CONTROL_DIV;
+    const uint32_t k = first < n_ticks ? 1u + (n_ticks - 1u - first) / MODPDM_CONTROL_DIV : 0u;
+    const uint64_t a = m->isr_count, b = a + k;                     // control_update's beat divider over k calls
+    m->beat_pulse += (uint32_t)((b + SMX_CONTROLRATE_BEAT_DIV - 1) / SMX_CONTROLRATE_BEAT_DIV -
+                                (a + SMX_CONTROLRATE_BEAT_DIV - 1) / SMX_CONTROLRATE_BEAT_DIV);
+    m->isr_count = (uint32_t)b;
+    m->control_div_count = (uint32_t)(((uint64_t)m->control_div_count + n_ticks) % MODPDM_CONTROL_DIV);
+    if (control_triggers) *control_triggers = k;
+    return SMX_OK;
+}

@@ -124,24 +124,29 @@ void poly_bank_kernel(smx::PolyArrays p, int32_t *__restrict__ slots /* [POLY_SL
         // sampled there).
         uint32_t flip, thr, delta, reach_val, next, down, floor_;
         auto enter = [&](uint32_t st) {
+            // (masks instead of select chains: the compiler turns a chain of `st == K ? x : ...` over several
+            // variables into a table in scratch memory indexed by st -- 168 bytes of private segment and a launch
+            // three times as long)
+            const uint32_t isA = 0u - (uint32_t)(st == ENV_A), isD = 0u - (uint32_t)(st == ENV_D);
+            const uint32_t isR = 0u - (uint32_t)(st == ENV_R), isS = 0u - (uint32_t)(st == ENV_S);
+            const uint32_t isI = 0u - (uint32_t)(st == ENV_IDLE);
             stage = st;
-            down = st == ENV_D ? dr : st == ENV_R ? rr : 0u;
-            floor_ = st == ENV_D ? sl : 0u;
-            if (st == ENV_S) level = sl;
-            if (st == ENV_IDLE) level = 0;
-            const uint32_t rate = st == ENV_A ? ar : st == ENV_D ? dr : st == ENV_R ? rr : 0u;
-            const uint32_t target = st == ENV_D ? sl : 0u;
-            const bool down = st == ENV_D || st == ENV_R;
+            level = (level & ~(isS | isI)) | (sl & isS);                 // S: level = sl; idle: level = 0
+            const uint32_t rate = (ar & isA) | (dr & isD) | (rr & isR);
+            const uint32_t target = sl & isD;
+            down = (dr & isD) | (rr & isR);
+            floor_ = target;
+            const bool is_down = (isD | isR) != 0u;
             const uint64_t lim = (uint64_t)target + rate + 1;
-            const bool always = down && (rate ? lim > 0xFFFFFFFFull : level <= target);
+            const bool always = is_down && (rate ? lim > 0xFFFFFFFFull : level <= target);
             const bool hold = !always && rate == 0;
-            flip = (st == ENV_A) ? 0xFFFFFFFFu : 0u;
-            thr = st == ENV_A ? ar : (uint32_t)lim;
-            delta = st == ENV_A ? ar : 0u - rate;
+            flip = isA;
+            thr = isA ? ar : (uint32_t)lim;
+            delta = isA ? ar : 0u - rate;
             if (always) { thr = 0xFFFFFFFFu; flip = level == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u; }
             if (hold) { thr = 0; flip = 0; delta = 0; }
-            reach_val = st == ENV_A ? 0xFFFFFFFFu : target;
-            next = st == ENV_A ? (uint32_t)ENV_D : st == ENV_D ? (uint32_t)ENV_S : (uint32_t)ENV_IDLE;
+            reach_val = isA | target;                                   // A: MAX; D: sl; R: 0
+            next = (ENV_D & isA) | (ENV_S & isD);                        // A -> D, D -> S, R -> idle (0)
         };
         enter(stage);
 
@@ -173,8 +178,10 @@ void poly_bank_kernel(smx::PolyArrays p, int32_t *__restrict__ slots /* [POLY_SL
             voice_out(i);
         };
         bool rising = __any(stage == ENV_A && ar != 0u);
+        bool fast_tail;                                                 // did the block's last frames run the short form?
         if (F64) {
             for (uint32_t i0 = 0; i0 < 64; i0 += 8) {
+                fast_tail = !rising;
                 if (rising) {
 #pragma unroll
                     for (uint32_t j = 0; j < 8; j++) frame(i0 + j);
@@ -185,12 +192,18 @@ void poly_bank_kernel(smx::PolyArrays p, int32_t *__restrict__ slots /* [POLY_SL
                 }
             }
         } else {
+            fast_tail = !rising;
             for (uint32_t i = 0; i < nframes; i++) {
                 if (rising) frame(i); else frame_down(i);
             }
         }
-        if (stage == ENV_D && level == sl) stage = ENV_S;               // arrivals the short form did not announce
-        if (stage == ENV_R && level == 0u) stage = ENV_IDLE;
+        // Arrivals the short form did not announce: a D that sits at sl is S, an R that sits at 0 is idle.  Only after
+        // frames of the short form (a lane then spent at least one frame in its stage): an attack that arrives in the
+        // block's very last frame of the general form has just ENTERED D and must stay D whatever its level.
+        if (fast_tail) {
+            if (stage == ENV_D && level == sl) stage = ENV_S;
+            if (stage == ENV_R && level == 0u) stage = ENV_IDLE;
+        }
         p.phase[v] = phase; p.level[v] = level; p.stage[v] = stage; p.y[v] = y;
       }
       v += gridDim.x * NT;
@@ -264,7 +277,9 @@ int launch_poly_bank(const PolyArrays &p, int32_t *d_bus_lr, int32_t *d_slots, u
     // the chip has room (LDS: 4 workgroups of 33 KB per CU), grid-stride above that.
     static const uint32_t env_nt = [] { const char *e = getenv("SMX_POLY_NT"); return e ? (uint32_t)atoi(e) : 0u; }();
     static const uint32_t env_gx = [] { const char *e = getenv("SMX_POLY_GRID"); return e ? (uint32_t)atoi(e) : 0u; }();
-    const uint32_t nt = (env_nt == 512 || env_nt == 1024 || env_nt == 256) ? env_nt : 256u;
+    // 512 threads: 8 waves share one LDS matrix and one fold (measured against 256 / 1024, tools/explore_poly.py:
+    // 256 Ki voices x 64 frames 11.8 / 12.2 / 11.9 us, 4 Mi voices 93 / 107 / 93 us)
+    const uint32_t nt = (env_nt == 512 || env_nt == 1024 || env_nt == 256) ? env_nt : 512u;
     const uint32_t rows = n_pad / nt;
     uint32_t gx = rows;
     const uint32_t cap = nt == 1024 ? 512u : 1024u;       // resident workgroups: 4 per CU (LDS), 8 waves per SIMD

@@ -68,6 +68,52 @@ def test_pwmosc_kernel_reproduces_reference_outputs(smx):
     bank.close()
 
 
+def test_mod_pdm_module_isr(smx, orc):
+    """mod_pdm.c's timer ISR as one call (mod_pdm.c:177-194): the carry-out channels, the PWM channel and the
+    control trigger every CONTROL_DIV ticks -- against the oracle's two loops (PDM: mod_pdm.c:214-286; pwm_update:
+    pinned by the reference itself) and the reference's own CONTROL_DIV (from the compiled :164, in the fixture)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pwmosc_reference.npz"))
+    div = int(g["control_div"])
+    assert div == 256
+    nch, nosc = 2, 1                                       # the firmware's configuration (mod_pdm.c:124-125)
+    for nch, nosc in ((2, 1), (70, 33)):
+        m = smx.ModPdm(nch, nosc)
+        sp, ac = m.pdm.read()
+        assert sp[0] == 2000000000 and (sp[1:] == 0x40000000).all() and not ac.any()      # pdm_init, mod_pdm.c:320-326
+        ph, spd = m.osc.read_pwm()
+        assert not ph.any() and (spd == int(g["default_speed"])).all()
+        rng = np.random.default_rng(177194 + nch)
+        if nch > 2:
+            sp = (0x40000000 + rng.integers(0, 0x80000001, nch)).astype(np.uint32)
+            m.pdm.load(sp, ac)
+            spd = rng.integers(1, 70000, nosc).astype(np.uint32)
+            m.osc.load_pwm(ph, spd)
+        o_ac, o_ph = ac.copy(), ph.copy()
+        count = triggers = isr = beat = 0
+        for nt in (1, 255, 1, 700, 3000):
+            dith = (rng.integers(0, 1 << 28, nt)).astype(np.uint32)                        # & 0x0FFFFFFF, mod_pdm.c:261
+            sync = rng.random((nt, m.osc.words * 32)) < 0.01
+            sync[:, nosc:] = False
+            sb = np.ascontiguousarray(np.packbits(sync.reshape(nt, m.osc.words, 32), axis=2, bitorder="little")
+                                      .view(np.uint32).reshape(nt, m.osc.words))
+            bits, duty, trig = m.tick_n(nt, dith, sb)
+            assert np.array_equal(bits, oracle.pdm_run(orc, sp, o_ac, nt, dith))
+            want = np.zeros((nt, nosc), np.uint8)
+            orc.orc_pwmosc_run(o_ph, spd, nosc, sb.ctypes.data, nt, want.ctypes.data)
+            assert np.array_equal(duty, want)
+            k = sum(1 for t in range(nt) if (count + t) % div == 0)                       # mod_pdm.c:184-192
+            assert trig == k
+            for _ in range(k):                                                            # mod_controlrate.c:52-55
+                beat += isr % 1024 == 0
+                isr += 1
+            count = (count + nt) % div
+            triggers += k
+            assert m.control_div_count == count and m.controlrate()[:2] == (isr, beat)
+        assert np.array_equal(m.pdm.read()[1], o_ac) and np.array_equal(m.osc.read_pwm()[0], o_ph)
+        assert triggers == (1 + 255 + 1 + 700 + 3000 + div - 1) // div
+        m.close()
+
+
 def test_pwmosc_defaults(smx, orc):
     """pwm_phase 0, pwm_speed 256*13 (mod_pdm.c:160-161)."""
     bank = smx.OscBank(2)
