@@ -672,11 +672,12 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
                  "value": round(n * 64 / (t * 1e-3) / 1e9, 2), "unit": "Gsamples/s", "ms_per_step": round(t, 5),
                  "roofline": roof(60.0 * n + 64 * 8, t, n * 64, ISSUE["poly"]), "verified": checked}
             e["hbm_frac"] = e["roofline"]["hbm_frac"]
-            # 14 (down-only envelope) .. 16 (general) instructions per voice-sample, mean 2.9-3.05 cycles each
-            with_recorded_issue(e, ("poly_bank_kernel",), 3.0)
-            e["roofline"]["bound"] = ("vector issue + LDS atomics, NOT overlapped at 4 waves per SIMD (256 Ki voices = 16 waves per CU: "
-                                      "32 ds_add x 4.2 cycles + 4 x 14..16 vector instructions x ~3 cycles per frame and CU, "
-                                      "profiles/r03_lds_rates.txt), on top of a 4.4 us one-frame launch")
+            # 14 (down-only envelope) .. 16 (general) instructions per voice-sample; 3.9 cycles each is what a SIMD with 8 waves
+            # sustains on this mix (4 Mi voices)
+            with_recorded_issue(e, ("poly_bank_kernel",), 3.9)
+            e["roofline"]["bound"] = ("vector issue at 4 waves per SIMD (256 Ki voices = 16 waves per CU; 14..16 dependent instructions "
+                                      "per voice-sample at 5.1 cycles each, 3.9 with 8 waves per SIMD) on top of a 4.4 us one-frame "
+                                      "launch; DESIGN 3.5")
             out.append(e)
     return out
 
