@@ -620,3 +620,57 @@ def test_deferred_slot_fold_sequences(smx, orc, inc_table):
         if step % 7 == 6 or step == 39:
             assert np.array_equal(bank.fetch(nf)[0], want), ("comm", step, nf)
     bank.close()
+
+
+@pytest.mark.parametrize("form", [1, 2, 0])
+def test_deferred_carry_finalize_sequences(smx, orc, inc_table, form):
+    """Round 3: while ONE long-block form is pinned (by the caller: form 1 stepping / 2 events; form 0: by the host after
+    four equal picks of AUTO) a carry launch of 64-frame chunks leaves its finalize to the next launch, which runs it
+    in its first workgroups, or to whoever needs the bus / changes the increments first.  Un-fetched long blocks in a
+    row (one chunk and several), every kind of successor (another long block of either chunk count, a 256+-frame
+    launch with its own slot layout, direct slot launches, the tick kernel, note events -- which must see the owed
+    finalize run BEFORE the pick is cleared --, a reload, the square variant): every fetched bus and the final phases
+    equal the oracle's, and AUTO's pick stays conservative after a high note."""
+    rng = np.random.default_rng(0xCA77 + form)
+    n = 1 << 24                                   # 2^24 voices x 64 frames = 2^30 voice-samples: the carry path
+    inc, state = synthetic.saw_bank(n, 0x5EED0F02, inc_table, active_fraction=0.9)
+    bank = smx.SawBank(n)
+    bank.load(inc, state)
+    bank.set_block_form(form)
+    st = state.copy()
+    inc = inc.copy()
+    n2v = np.zeros(128, np.int32)
+    frames = [64, 64, 64, 128, 100, 65, 256, 300, 16, 8, 1, 3, 33]
+    checked = 0
+    for step in range(60):
+        nf = int(rng.choice(frames)) if step >= 8 else 64         # a run of long blocks first (AUTO: the host pins)
+        r = rng.random()
+        if step >= 8 and r < 0.10:
+            note = int(rng.integers(0, 128))
+            bank.note_on(note)
+            orc.orc_note_on(n2v, inc, n, note)
+        elif step >= 8 and r < 0.14:
+            bank.load(inc=inc)                                       # same increments: exercises the flush before a reload
+        elif step >= 8 and r < 0.18:
+            got = bank.run_square(2)
+            want = np.array([orc.orc_sum_tick_square(inc, st, n) for _ in range(2)], np.float32)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), ("square", step)
+            continue
+        bank.run_async(nf)
+        want, _ = oracle.synth_run(orc, inc, st, nf, want_vec=False)
+        if rng.random() < 0.3 or step in (7, 59):
+            bus, _ = bank.fetch(nf)
+            assert np.array_equal(bus, want), ("bus", form, step, nf)
+            checked += 1
+    assert checked >= 10
+    if form == 0:
+        # a note far above the rule's bound: the very next long block must step, whatever finalizes were in flight
+        bank.note_on(127)
+        orc.orc_note_on(n2v, inc, n, 127)
+        assert bank.next_block_form() == 1
+        bank.run_async(64)
+        want, _ = oracle.synth_run(orc, inc, st, 64, want_vec=False)
+        assert np.array_equal(bank.fetch(64)[0], want)
+    ginc, gst = bank.read()
+    assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+    bank.close()
