@@ -435,9 +435,7 @@ extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *s
 {
     if (!b) { set_error("smx_bank_load: null bank"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
-    int rv = bank_flush_fold(b);             // an owed finalize belongs to the old increments
-    if (rv) return rv;
-    rv = bank_materialize(b);                // an array that is not replaced keeps its meaning
+    int rv = bank_materialize(b);            // an array that is not replaced keeps its meaning
     if (rv) return rv;
     SMX_HIP(hipStreamSynchronize(b->stream));
     if (inc) {
@@ -502,11 +500,7 @@ static int bank_set_inc(smx_bank *b, uint32_t v, uint32_t inc)
     uint32_t local;
     if (!bank_owns(b, v, &local)) return SMX_OK;
     SMX_HIP(hipSetDevice(b->device));
-    // a long block may still owe its finalize (it reads the bank's sum of increments and writes the form pick): it
-    // must run BEFORE this event changes the sum and clears the pick, or a stale pick would outlive the event
-    int rv = bank_flush_fold(b);
-    if (rv) return rv;
-    rv = smx::launch_saw_rebase(b->d_inc, b->d_state0, local, inc, b->elapsed, b->d_scratch, b->n_pad, b->stream);
+    int rv = smx::launch_saw_rebase(b->d_inc, b->d_state0, local, inc, b->elapsed, b->d_scratch, b->n_pad, b->stream);
     if (rv) return rv;
     bank_form_unpin(b);
     return SMX_OK;
@@ -746,10 +740,6 @@ extern "C" int smx_bank_midi_events(smx_bank *b, const uint8_t *msgs3, size_t n_
         }
     }
     if (npairs == 0) return SMX_OK;
-    {
-        int rv = bank_flush_fold(b);             // as in bank_set_inc: an owed finalize runs before the increments change
-        if (rv) return rv;
-    }
     SMX_HIP(hipMemcpyAsync(b->d_ev, pairs, (size_t)npairs * 8, hipMemcpyHostToDevice, b->stream));
     SMX_HIP(hipEventRecord(b->ev_stage[k], b->stream));
     b->ev_stage_busy[k] = true;
@@ -880,10 +870,6 @@ extern "C" int smx_bank_next_block_form(smx_bank *b)
     if (b->block_form != SMX_FORM_AUTO) return b->block_form;
     if (!b->d_scratch) return SMX_FORM_STEPPING;
     SMX_HIP(hipSetDevice(b->device));
-    {
-        int rv = bank_flush_fold(b);             // the last long block's finalize writes the pick
-        if (rv) return rv;
-    }
     SMX_HIP(hipStreamSynchronize(b->stream));
     uint32_t pick = 0;
     SMX_HIP(hipMemcpy(&pick, b->d_scratch, 4, hipMemcpyDeviceToHost));

@@ -407,24 +407,6 @@ __device__ __forceinline__ uint32_t div_small(uint32_t a, uint32_t d, float rd)
     return r >= d ? q + 1u : q;
 }
 
-struct SawFoldLds {                      // LDS of saw_carry_fold (defined with the finalize kernels below)
-    unsigned long long Ls[4][64], Us[4][1];
-    uint32_t Ws[4][64], Mx[4];
-};
-__device__ __forceinline__
-void saw_carry_fold(SawPartial *__restrict__ partial, int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
-                    uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag,
-                    uint32_t *__restrict__ host_flag, uint32_t host_tag, uint32_t row, SawFoldLds &lds);
-
-// The finalize a carry launch still owes for its PREDECESSOR (smx::SawPending, kind 1): 64-frame rows of `partial`.
-struct SawOwedCarry {
-    SawPartial *partial;                 // nullptr: nothing owed
-    int32_t *bus, *bus_next;
-    uint32_t nframes, nvoices;
-    uint32_t *hdr, *host_flag;
-    uint32_t host_tag;
-};
-
 // MULTI: more than one 64-frame chunk per launch (blockIdx.y).
 // TC: frames computed per chunk (64; blocks of up to 32 frames run the direct form, which is faster there since
 //   its accumulate became plain adds: 64 Mi voices x 32 frames 135 us against 138 us for a 32-frame stepping chunk).
@@ -441,12 +423,11 @@ template <bool NT, bool MULTI, int TC, bool EVENTS, bool WIDE = false>
 __global__ __launch_bounds__(256)
 void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
                            SawPartial *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
-                           const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long, SawOwedCarry owed)
+                           const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
 {
     static_assert(!EVENTS || TC == 64, "the event form is built for 64-frame chunks");
     static_assert(TC == 64, "frames per chunk");
-    __shared__ __align__(16) uint32_t M[64][65];   // [frame][lane] carry counts; column 64: scalar counts
-    static_assert(sizeof(SawFoldLds) <= sizeof(uint32_t) * 64 * 65, "the owed fold borrows M");
+    __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
     __shared__ unsigned long long S[1];            // U0
     __shared__ uint32_t MX;                        // largest increment
@@ -454,17 +435,6 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     if (mode_flag && (*mode_flag != 0u) != EVENTS) return;     // the other form runs this launch
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if (ran_long && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ran_long = 0;   // 64-frame slot layout
-    // The previous long block left its finalize to this launch (only while a form is pinned: mode_flag is null then, so
-    // nobody reads the pick this writes): the first workgroups take one 64-frame row each, in M's memory, before M
-    // is cleared for this launch's own counts.  The other slot region, so no clash with this launch's atomics.
-    if (owed.partial) {
-        const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
-        if (wg < (owed.nframes + 63u) / 64u) {
-            saw_carry_fold(owed.partial, owed.bus, owed.bus_next, owed.nframes, owed.nvoices, owed.hdr, owed.host_flag,
-                           owed.host_tag, wg, *reinterpret_cast<SawFoldLds *>(&M[0][0]));
-            __syncthreads();
-        }
-    }
     const uint32_t t0 = tbase + (MULTI ? blockIdx.y * 64u : 0u);   // phase offset of this chunk
     for (uint32_t i = tid; i < 64 * 65; i += 256) (&M[0][0])[i] = 0;
     H[tid] = 0;
@@ -886,17 +856,32 @@ __device__ __forceinline__ void saw_finalize_long(SawPartialL<TL> *__restrict__ 
     }
 }
 
-// The finalize of ONE 64-frame row of slots (256 threads): add the row's slots (and clear them for the next launch), emit
+// One workgroup per 64-frame chunk: add the chunk's slots (and clear them for the next
+// launch) and emit
 //   bus[t0+t] = ((U0 + t*I - 2^32*W(t) - L(t)) >> 4) - nvoices * 2^27        (mod 2^32)
-// and, for row 0, refresh the statistic that picks the next long block's form.  The caller provides 3.1 KB of LDS.
-__device__ __forceinline__
-void saw_carry_fold(SawPartial *__restrict__ partial, int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
-                    uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag,
-                    uint32_t *__restrict__ host_flag, uint32_t host_tag, uint32_t row, SawFoldLds &lds)
+__global__ __launch_bounds__(256)
+void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
+                              int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
+                              uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag,
+                              const uint32_t *__restrict__ ran_long, uint32_t *__restrict__ host_flag,
+                              uint32_t host_tag)
 {
-    auto &Ls = lds.Ls; auto &Us = lds.Us; auto &Ws = lds.Ws; auto &Mx = lds.Mx;
+    // which slot layout did this launch fill?  (written by the main kernel that ran, stable here)
+    if (ran_long && *ran_long != 0u) {
+        if (*ran_long == 1u) {
+            if (blockIdx.x * 256u < nframes)
+                saw_finalize_long<256>(reinterpret_cast<SawPartialL<256> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag, host_tag);
+        } else {
+            if (blockIdx.x * 1024u < nframes)
+                saw_finalize_long<1024>(reinterpret_cast<SawPartialL<1024> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag, host_tag);
+        }
+        return;
+    }
+    if (blockIdx.x * 64u >= nframes) return;
+    __shared__ unsigned long long Ls[4][64], Us[4][1];
+    __shared__ uint32_t Ws[4][64], Mx[4];
     const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
-    SawPartial *p = partial + (size_t)row * SAW_SLOTS;
+    SawPartial *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
     // all loads first (16 independent ones per thread in flight), then the clearing stores
     unsigned long long lv[SAW_SLOTS / 4], uv[SAW_SLOTS / 4];
     uint32_t wv[SAW_SLOTS / 4];
@@ -940,7 +925,7 @@ void saw_carry_fold(SawPartial *__restrict__ partial, int32_t *__restrict__ bus,
         const uint32_t wraps = incl - mine;
         const unsigned long long x = U0 + (unsigned long long)t * I - ((unsigned long long)(wraps & 15u) << 32) - L;
         const uint32_t r = (uint32_t)(x >> 4) - (nvoices << 27);
-        const uint32_t f = row * 64u + t;
+        const uint32_t f = blockIdx.x * 64u + t;
         if (f < nframes) {
             bus[f] = (int32_t)r;
             bus_next[f] = 0;                        // same contract as saw_bank_kernel
@@ -950,38 +935,12 @@ void saw_carry_fold(SawPartial *__restrict__ partial, int32_t *__restrict__ bus,
         // is at most 2 wraps per voice (sum of inc <= voices * 2^27).  Measured on 64 Mi voices x
         // 64 frames (stepping: 236 us): piano-range bank 18x us, all voices at 2 wraps 123 us, at 6
         // wraps 269 us, 1 % of the voices at 12 wraps 243 us, all at 12 wraps 750 us.
-        if (row == 0 && t == 0 && mode_flag) {
+        if (blockIdx.x == 0 && t == 0 && mode_flag) {
             const uint32_t m = max(max(Mx[0], Mx[1]), max(Mx[2], Mx[3]));
             const uint32_t fl = (m < SAW_EVENTS_MAX_INC && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
             saw_stats_publish(mode_flag, host_flag, fl, host_tag);
         }
     }
-}
-
-// One workgroup per 64-frame chunk: add the chunk's slots (and clear them for the next
-// launch) and emit
-//   bus[t0+t] = ((U0 + t*I - 2^32*W(t) - L(t)) >> 4) - nvoices * 2^27        (mod 2^32)
-__global__ __launch_bounds__(256)
-void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
-                              int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
-                              uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag,
-                              const uint32_t *__restrict__ ran_long, uint32_t *__restrict__ host_flag,
-                              uint32_t host_tag)
-{
-    // which slot layout did this launch fill?  (written by the main kernel that ran, stable here)
-    if (ran_long && *ran_long != 0u) {
-        if (*ran_long == 1u) {
-            if (blockIdx.x * 256u < nframes)
-                saw_finalize_long<256>(reinterpret_cast<SawPartialL<256> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag, host_tag);
-        } else {
-            if (blockIdx.x * 1024u < nframes)
-                saw_finalize_long<1024>(reinterpret_cast<SawPartialL<1024> *>(partial), bus, bus_next, nframes, nvoices, mode_flag, host_flag, host_tag);
-        }
-        return;
-    }
-    if (blockIdx.x * 64u >= nframes) return;
-    __shared__ SawFoldLds lds;
-    saw_carry_fold(partial, bus, bus_next, nframes, nvoices, mode_flag, host_flag, host_tag, blockIdx.x, lds);
 }
 
 // sum_tick_square (linux/synth.c:182-195): OR of the active voices' sign bits.
@@ -1130,16 +1089,9 @@ static uint32_t grid_size(uint32_t tc, uint32_t rows, uint32_t gy)
 int flush_pending(smx::SawPending *pend, hipStream_t stream)
 {
     if (!pend || !pend->partial) return SMX_OK;
-    if (pend->kind == 1)
-        hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3((pend->nframes + 63) / 64), dim3(256), 0, stream,
-                           static_cast<SawPartial *>(pend->partial), pend->bus, pend->bus_next, pend->nframes,
-                           pend->nvoices, pend->hdr, (const uint32_t *)nullptr /* 64-frame slot layout */,
-                           pend->host_flag, pend->host_tag);
-    else
-        hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3((pend->nframes + 63) / 64), dim3(256), 0, stream,
-                           static_cast<SawPartial *>(pend->partial), pend->bus, pend->bus_next, pend->nframes);
+    hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3((pend->nframes + 63) / 64), dim3(256), 0, stream,
+                       static_cast<SawPartial *>(pend->partial), pend->bus, pend->bus_next, pend->nframes);
     pend->partial = nullptr;
-    pend->kind = 0;
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
@@ -1166,8 +1118,8 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
             SawOwed owed{nullptr, nullptr, nullptr, 0};
             if (pend && pend->region_stride) {
                 // deferred fold: this launch folds its predecessor's slots and fills the other region
-                if (pend->partial && (pend->kind != 0 || (pend->nframes + 63) / 64 > gx * gy)) {
-                    const int rv = flush_pending(pend, stream);       // a carry launch's finalize, or too many rows
+                if (pend->partial && (pend->nframes + 63) / 64 > gx * gy) {
+                    const int rv = flush_pending(pend, stream);
                     if (rv) return rv;
                 }
                 if (pend->partial)
@@ -1178,7 +1130,6 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
                                inc, si, bus, bus_next, ngroups, nframes, tbase, partial, owed);
             if (pend && pend->region_stride) {
                 pend->partial = partial;
-                pend->kind = 0;
                 pend->bus = bus;
                 pend->bus_next = bus_next;
                 pend->nframes = nframes;
@@ -1272,27 +1223,14 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
         // (banks that would need more workgroups than the scratch holds use the direct form)
         const uint32_t trips = (ngroups + gx * 256u - 1) / (gx * 256u);
         if (trips <= 400 && (size_t)SAW_SLOTS * gy * sizeof(SawPartial) <= saw_scratch_region_bytes(nframes)) {
+            {
+                const int rv = flush_pending(pend, stream);       // the slots must be all zero, the bus cleared
+                if (rv) return rv;
+            }
             auto *flag = static_cast<uint32_t *>(d_scratch);
             auto *part = reinterpret_cast<SawPartial *>(static_cast<char *>(d_scratch) + SAW_SCRATCH_HEADER);   // all zero between launches
             const bool no_events = long_block_form == SMX_FORM_STEPPING;
             const bool force_events = long_block_form == SMX_FORM_EVENTS;
-            // Round 3: while ONE form is pinned (no kernel reads the pick) a 64-frame-chunk launch leaves its finalize
-            // to its successor, which runs it in its first workgroups (the two slot regions alternate) -- the stream
-            // carries one kernel per long block instead of two (saw_bank_finalize_kernel as a launch of its own is
-            // 7.2 us: 5 % of a 64 Mi-voice JACK block).  Everything else -- AUTO with both forms queued, the long
-            // event layouts, a caller who needs the bus -- finalizes on the spot, after any owed fold.
-            static const bool no_long_env = getenv("SMX_SAW_NO_LONG_EVENTS") != nullptr;
-            const bool long_layout = nframes >= SAW_LONG && !no_long_env && !no_events;
-            const bool defer = pend && pend->region_stride && (no_events || force_events) && !long_layout;
-            SawOwedCarry owed{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
-            if (defer && pend->partial && pend->kind == 1 && (pend->nframes + 63) / 64 <= gx * gy) {
-                owed = SawOwedCarry{static_cast<SawPartial *>(pend->partial), pend->bus, pend->bus_next, pend->nframes,
-                                    pend->nvoices, pend->hdr, pend->host_flag, pend->host_tag};
-            } else {
-                const int rv = flush_pending(pend, stream);       // the slots must be all zero, the bus cleared
-                if (rv) return rv;
-            }
-            if (defer) part = reinterpret_cast<SawPartial *>(reinterpret_cast<char *>(part) + pend->region * pend->region_stride);
             // the event form's rows take unequal time: more, shorter workgroups balance better
             // (64 Mi voices: 64 frames 198 us with 2048, 189 with 4096; 1024 frames 2.68 / 2.56 ms with 4096 / 8192)
             uint32_t gx_ev = ((cg ? (uint32_t)atoi(cg) : (gy == 1 ? 4096u : 8192u)) + gy - 1) / gy;
@@ -1301,7 +1239,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             static const bool wide = getenv("SMX_SAW_NO_WIDE") == nullptr;          // A/B switch: carry masks instead of 64-bit pairs
 #define SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, W_, FLAG_)                                                  \
     hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, EV_, W_>), dim3((EV_) ? gx_ev : gx, gy),    \
-                       dim3(256), 0, stream, d_inc, d_state_in, part, ngroups, tbase, FLAG_, ran_long, owed)
+                       dim3(256), 0, stream, d_inc, d_state_in, part, ngroups, tbase, FLAG_, ran_long)
 #define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_, EV_, FLAG_)                                                        \
     do {                                                                                                      \
         if ((EV_) || !wide) SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, false, FLAG_);                          \
@@ -1344,21 +1282,8 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             }
 #undef SMX_CARRY_LAUNCH
 #undef SMX_CARRY_LAUNCH_W
-            if (defer) {
-                pend->partial = part;
-                pend->kind = 1;
-                pend->bus = d_bus;
-                pend->bus_next = d_bus_next;
-                pend->nframes = nframes;
-                pend->nvoices = n_pad;
-                pend->hdr = flag;
-                pend->host_flag = host_flag;
-                pend->host_tag = host_tag;
-                pend->region ^= 1u;
-            } else {
-                hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
-                                   d_bus_next, nframes, n_pad, flag, ran_long, host_flag, host_tag);
-            }
+            hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
+                               d_bus_next, nframes, n_pad, flag, ran_long, host_flag, host_tag);
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         }

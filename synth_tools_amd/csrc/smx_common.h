@@ -54,12 +54,6 @@ struct SawPending {
     void *partial = nullptr;            // slots of the block whose fold is owed (nullptr: nothing owed)
     int32_t *bus = nullptr, *bus_next = nullptr;
     uint32_t nframes = 0;
-    // Round 3: the carry formulations defer their finalize the same way while ONE form is pinned (by the caller or by
-    // the host after stable picks: then no kernel reads the device's pick, which the finalize writes).  kind 1: the
-    // owed fold is saw_bank_finalize_kernel's (64-frame slot layout), with what it needs besides the slots.
-    int kind = 0;
-    uint32_t nvoices = 0, host_tag = 0;
-    uint32_t *hdr = nullptr, *host_flag = nullptr;
     uint32_t region = 0;                // slot region the NEXT slot launch fills
     size_t region_stride = 0;           // bytes between the two regions: saw_scratch_region_bytes(cap the scratch has)
 };

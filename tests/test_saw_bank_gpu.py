@@ -623,14 +623,14 @@ def test_deferred_slot_fold_sequences(smx, orc, inc_table):
 
 
 @pytest.mark.parametrize("form", [1, 2, 0])
-def test_deferred_carry_finalize_sequences(smx, orc, inc_table, form):
-    """Round 3: while ONE long-block form is pinned (by the caller: form 1 stepping / 2 events; form 0: by the host after
-    four equal picks of AUTO) a carry launch of 64-frame chunks leaves its finalize to the next launch, which runs it
-    in its first workgroups, or to whoever needs the bus / changes the increments first.  Un-fetched long blocks in a
-    row (one chunk and several), every kind of successor (another long block of either chunk count, a 256+-frame
-    launch with its own slot layout, direct slot launches, the tick kernel, note events -- which must see the owed
-    finalize run BEFORE the pick is cleared --, a reload, the square variant): every fetched bus and the final phases
-    equal the oracle's, and AUTO's pick stays conservative after a high note."""
+def test_long_block_sequences_with_a_pinned_form(smx, orc, inc_table, form):
+    """Long blocks of a 2^24-voice bank (the carry formulations) with a form pinned by the caller (1 stepping, 2 events)
+    or, under AUTO (0), by the host after four equal picks: un-fetched long blocks in a row (one chunk and several),
+    every kind of successor (another long block of either chunk count, a 256+-frame launch with its own slot layout,
+    direct slot launches, the tick kernel, note events, a reload, the square variant): every fetched bus and the
+    final phases equal the oracle's, and AUTO's pick stays conservative after a high note.  (Written for round 3's
+    attempt to defer the carry forms' finalize to the next launch -- measured slower and reverted; the
+    sequences stay as a test of the long-block path.)"""
     rng = np.random.default_rng(0xCA77 + form)
     n = 1 << 24                                   # 2^24 voices x 64 frames = 2^30 voice-samples: the carry path
     inc, state = synthetic.saw_bank(n, 0x5EED0F02, inc_table, active_fraction=0.9)
