@@ -419,8 +419,11 @@ __device__ __forceinline__ uint32_t div_small(uint32_t a, uint32_t d, float rd)
 // x 64 frames 236 -> 18x us -- but the loop runs as long as the busiest voice of the wave, so banks
 // with many high voices are slower this way (all voices at 12 wraps: 3x).  The finalize kernel
 // keeps the statistic that picks the form (mode_flag; see SAW_SCRATCH_HEADER).
-template <bool NT, bool MULTI, int TC, bool EVENTS, bool WIDE = false>
-__global__ __launch_bounds__(256)
+// NTH: threads per workgroup.  The event form keeps a 2 KB list per wave next to the counting matrix: with 256 threads
+// that is 25.9 KB per workgroup, 6 workgroups = 6 waves per SIMD on a CU's 160 KB; 512 threads share one matrix and
+// one histogram (34 KB per workgroup, 4 of them: 8 waves per SIMD, which the kernel's 61 vector registers allow).
+template <bool NT, bool MULTI, int TC, bool EVENTS, bool WIDE = false, int NTH = 256>
+__global__ __launch_bounds__(NTH)
 void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
                            SawPartial *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
                            const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
@@ -431,13 +434,13 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
     __shared__ unsigned long long S[1];            // U0
     __shared__ uint32_t MX;                        // largest increment
-    __shared__ uint2 EL[EVENTS ? 4 * 256 : 1];     // EVENTS: per wave, the (phase, inc) of the voices that wrap
+    __shared__ uint2 EL[EVENTS ? (NTH / 64) * 256 : 1];     // EVENTS: per wave, the (phase, inc) of the voices that wrap
     if (mode_flag && (*mode_flag != 0u) != EVENTS) return;     // the other form runs this launch
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if (ran_long && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ran_long = 0;   // 64-frame slot layout
     const uint32_t t0 = tbase + (MULTI ? blockIdx.y * 64u : 0u);   // phase offset of this chunk
-    for (uint32_t i = tid; i < 64 * 65; i += 256) (&M[0][0])[i] = 0;
-    H[tid] = 0;
+    for (uint32_t i = tid; i < 64 * 65; i += NTH) (&M[0][0])[i] = 0;
+    if (tid < 256) H[tid] = 0;
     if (tid < 2) S[tid] = 0;
     if (tid == 0) MX = 0;
     __syncthreads();
@@ -455,21 +458,20 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
 
     // ngroups is a multiple of 256 (n_pad of 1024): whole workgroup rows, so the trip count is
     // wave-uniform and the scalar counters W stay in SGPRs
-    const uint32_t nrows = ngroups >> 8;
+    const uint32_t nrows = ngroups / (uint32_t)NTH;     // the launcher picks NTH so that it divides ngroups
     // software prefetch: the next row's 32 bytes per lane are requested before the ~6000
     // cycles of arithmetic on the current row, so HBM latency never sits on the critical path
     const u32x4 *inc4 = reinterpret_cast<const u32x4 *>(inc);
     const u32x4 *st4 = reinterpret_cast<const u32x4 *>(st_in);
     u32x4 a_next = 0, b_next = 0;
     if (blockIdx.x < nrows) {
-        a_next = stream_load<NT>(inc4 + blockIdx.x * 256u + tid);
-        b_next = stream_load<NT>(st4 + blockIdx.x * 256u + tid);
+        a_next = stream_load<NT>(inc4 + blockIdx.x * (uint32_t)NTH + tid);
+        b_next = stream_load<NT>(st4 + blockIdx.x * (uint32_t)NTH + tid);
     }
     for (uint32_t row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const uint32_t g = row * 256u + tid;
         const u32x4 a = a_next, b = b_next;
         // unconditional prefetch (the last trip re-reads its own row): no branch, no join
-        const uint32_t rn = min(row + gridDim.x, nrows - 1) * 256u + tid;
+        const uint32_t rn = min(row + gridDim.x, nrows - 1) * (uint32_t)NTH + tid;
         a_next = stream_load<NT>(inc4 + rn);
         b_next = stream_load<NT>(st4 + rn);
         // an inactive voice (inc == 0) is parked at phase 0: it contributes (0 >> 4) = 0
@@ -581,7 +583,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     __syncthreads();
 
     SawPartial *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
-    {   // carries per frame: 4 lanes x 16 columns (+ column 64)
+    if (tid < 256) {   // carries per frame: 4 lanes x 16 columns (+ column 64)
         const uint32_t t = tid >> 2, q = tid & 3;
         uint32_t s = (q == 0) ? M[t][64] : 0u;
 #pragma unroll
@@ -590,7 +592,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         s += __shfl_xor(s, 2);
         if (q == 0) atomicAdd(&out->W[t], s);
     }
-    {   // low-nibble sums per frame from the histogram: 4 lanes x 64 bins per frame.  A workgroup
+    if (tid < 256) {   // low-nibble sums per frame from the histogram: 4 lanes x 64 bins per frame.  A workgroup
         // sees at most 400 rows x 1024 voices < 2^19 voices (launch_saw_bank), a bin count fits 24
         // bits and 64 bins x count x 15 < 2^31: 32-bit v_mad_u32_u24 sums, widened at the end.
         const uint32_t t = tid >> 2, q = tid & 3;
@@ -1237,12 +1239,19 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             if (gx_ev > (ngroups + 255) / 256) gx_ev = (ngroups + 255) / 256;
             uint32_t *ran_long = flag + 1;                    // which slot layout the launch filled
             static const bool wide = getenv("SMX_SAW_NO_WIDE") == nullptr;          // A/B switch: carry masks instead of 64-bit pairs
+            // the event form in 512-thread workgroups (8 instead of 6 waves per SIMD); A/B: SMX_SAW_EVENTS_256=1
+            static const bool ev256_env = getenv("SMX_SAW_EVENTS_256") != nullptr;
+            const bool ev512 = !ev256_env && (ngroups % 512u) == 0;
 #define SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, W_, FLAG_)                                                  \
     hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, EV_, W_>), dim3((EV_) ? gx_ev : gx, gy),    \
                        dim3(256), 0, stream, d_inc, d_state_in, part, ngroups, tbase, FLAG_, ran_long)
 #define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_, EV_, FLAG_)                                                        \
     do {                                                                                                      \
-        if ((EV_) || !wide) SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, false, FLAG_);                          \
+        if ((EV_) && ev512)                                                                                   \
+            hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, true, false, 512>),                   \
+                               dim3((gx_ev + 1) / 2, gy), dim3(512), 0, stream, d_inc, d_state_in, part,      \
+                               ngroups, tbase, FLAG_, ran_long);                                              \
+        else if ((EV_) || !wide) SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, false, FLAG_);                     \
         else                SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, false, true, FLAG_);                         \
     } while (0)
             const bool nt = n_pad >= (1u << 24);

@@ -105,3 +105,37 @@ def test_pdm_pwm_poly_bad_calls(smx, orc):
     assert L.smx_osc_events(o._h, 0, None, None) == 0
     assert L.smx_osc_events(o._h, 3, None, None) == E_ARG
     o.close()
+
+
+def test_published_bus_poll_is_bounded(smx):
+    """smx_bank_fetch polls the sequence word that the stream's last kernel writes to pinned host memory; the poll must
+    never spin forever (a lost device on a real-time thread).  With SMX_PUBLISH_TIMEOUT_MS=0 and a launch of a few
+    hundred microseconds the call returns SMX_E_NOGPU with a message instead of the bus, the process goes on, and
+    once the stream has drained the bank is intact (the block DID run: the phases have advanced by its frames)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import synth_tools_amd as sta
+        L = sta.lib()
+        n = 1 << 26
+        inc = np.full(n, 12345, np.uint32); st = np.zeros(n, np.uint32)
+        b = sta.SawBank(n); b.load(inc, st)
+        vec = np.zeros(64, np.float32)
+        rv = L.smx_bank_run(b._h, vec.ctypes.data, None, 64)
+        msg = L.smx_last_error().decode()
+        assert rv == -10, rv                                  # SMX_E_NOGPU
+        assert "did not publish" in msg, msg
+        b.sync()
+        ginc, gst = b.read()
+        assert (gst == np.uint32(64 * 12345)).all()
+        print("bounded")
+    """) % root
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMX_PUBLISH_TIMEOUT_MS="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "bounded" in p.stdout, p.stderr[-2000:]
