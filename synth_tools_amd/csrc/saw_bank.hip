@@ -1241,13 +1241,14 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             static const bool wide = getenv("SMX_SAW_NO_WIDE") == nullptr;          // A/B switch: carry masks instead of 64-bit pairs
             // the event form in 512-thread workgroups (8 instead of 6 waves per SIMD); A/B: SMX_SAW_EVENTS_256=1
             static const bool ev256_env = getenv("SMX_SAW_EVENTS_256") != nullptr;
+            // (1024-thread workgroups measured too: equal -- piano-range bank 124.8 vs 125.6 us on one box)
             const bool ev512 = !ev256_env && (ngroups % 512u) == 0;
 #define SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, W_, FLAG_)                                                  \
     hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, EV_, W_>), dim3((EV_) ? gx_ev : gx, gy),    \
                        dim3(256), 0, stream, d_inc, d_state_in, part, ngroups, tbase, FLAG_, ran_long)
 #define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_, EV_, FLAG_)                                                        \
     do {                                                                                                      \
-        if ((EV_) && ev512)                                                                                   \
+        if ((EV_) && ev512)                                                                              \
             hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, true, false, 512>),                   \
                                dim3((gx_ev + 1) / 2, gy), dim3(512), 0, stream, d_inc, d_state_in, part,      \
                                ngroups, tbase, FLAG_, ran_long);                                              \
