@@ -1337,7 +1337,12 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     static const char *tcc = getenv("SMX_SAW_TC_CAP");                  // tuning overrides
     static const char *svw = getenv("SMX_SAW_SMALL_VW");
     static const char *stc = getenv("SMX_SAW_SMALL_TC");
-    const uint32_t tc_cap = tcc ? (uint32_t)atoi(tcc) : 64u;
+    // 2 Mi .. 8 Mi voices: 16-frame chunks on blockIdx.y.  A 64-frame chunk keeps 64 per-frame sums per lane (100
+    // vector registers: 5 waves per SIMD) and gives a 2 Mi-voice bank only 2048 workgroups; four 16-frame chunks are
+    // 8192 workgroups of a 61-register kernel, and a bank of this size is re-read from the Infinity Cache, not from HBM
+    // (tools/explore_tc_cap.py, 64-frame blocks: 2 Mi voices 15.1 -> 12.0 us, 4 Mi 23.7 -> 20.9 us; 1 Mi voices equal,
+    // 8.0 us either way; banks from 16 Mi voices up would read HBM once per chunk and keep 64)
+    const uint32_t tc_cap = tcc ? (uint32_t)atoi(tcc) : (n_pad >= (1u << 21) && n_pad < (1u << 24)) ? 16u : 64u;
     if (n_pad >= (1u << 24))
         return launch_vw<4, true>(d_inc, d_state_in, d_bus, d_bus_next, n_pad, nframes, tbase, part, tc_cap, stream, pend);
     if (n_pad >= (1u << 20))
