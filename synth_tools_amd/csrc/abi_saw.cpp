@@ -172,6 +172,7 @@ struct smx_bank {
     int ar_frames[NBUS] = {};
     int ar_count = 0;
     int comm_group = 8;                          // blocks per collective (smx_bank_set_comm_group, 1 .. NBUS/2)
+    int last_comm_ev = -1;                       // ev_comm[] index recorded behind the youngest collective on the comm stream
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int comm_count = 0;                          // ncclCommCount: ranks the communicator really spans
@@ -216,6 +217,11 @@ static inline bool bank_owns(const smx_bank *b, uint32_t v, uint32_t *local)
 // Whoever is about to read the current bus buffer (or to write the next one outside a saw launch) first runs the
 // fold the last slot launch deferred; a no-op when nothing is owed.
 static int bank_flush_fold(smx_bank *b) { return smx::launch_saw_flush(&b->pend, b->stream); }
+// ... and may let that fold hand the bus to the host itself (a block of <= 64 frames ends in one workgroup of it)
+static int bank_flush_fold_pub(smx_bank *b, const smx::SawPublish *pub, bool *published)
+{
+    return smx::launch_saw_flush(&b->pend, b->stream, pub, published);
+}
 
 static int bank_ensure_bus(smx_bank *b, uint32_t n)
 {
@@ -572,6 +578,7 @@ static int bank_comm_flush(smx_bank *b)
         SMX_NCCL(ncclGroupEnd());
     }
     SMX_HIP(hipEventRecord(b->ev_comm[last], b->comm_stream));
+    b->last_comm_ev = last;
     for (int k = 0; k < b->ar_count; k++) {
         b->comm_pending[b->ar_queue[k]] = true;
         b->ev_owner[b->ar_queue[k]] = last;
@@ -631,7 +638,12 @@ static int bank_bus_advance(smx_bank *b, uint32_t n, int *bi_out, int *bnext_out
     return SMX_OK;
 }
 
-extern "C" int smx_bank_run_async(smx_bank *b, int n)
+static int bank_run_async(smx_bank *b, int n, const smx::SawPublish *pub, bool *published);
+extern "C" int smx_bank_run_async(smx_bank *b, int n) { return bank_run_async(b, n, nullptr, nullptr); }
+
+// pub: the caller will fetch this block at once (the synchronous smx_bank_run): if the block's last kernel is a
+// one-workgroup finalize, it publishes the bus itself (*published) and no publish kernel follows.
+static int bank_run_async(smx_bank *b, int n, const smx::SawPublish *pub, bool *published)
 {
     if (!b || n <= 0) { set_error("smx_bank_run_async: bad args"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
@@ -655,7 +667,7 @@ extern "C" int smx_bank_run_async(smx_bank *b, int n)
             form = b->form_seen ? SMX_FORM_EVENTS : SMX_FORM_STEPPING;
     }
     rv = smx::launch_saw_bank(b->d_inc, b->d_state0, b->d_bus[bi], b->d_bus[bnext], b->n_pad, (uint32_t)n,
-                              b->elapsed, b->d_scratch, form, b->h_form, b->long_tag, b->stream, &b->pend);
+                              b->elapsed, b->d_scratch, form, b->h_form, b->long_tag, b->stream, &b->pend, pub, published);
     if (rv) return rv;
     b->elapsed += (uint32_t)n;             // mod 2^32, like the phases
     b->bus_zeroed[bi] = 0;                 // now holds this block's sums
@@ -819,13 +831,27 @@ int bank_dropin_run(smx_bank *b, const uint32_t *inc, const uint32_t *state, flo
 }
 }  // namespace smx
 
-extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
+// have_seq != 0: the block's own last kernel has already been told to publish under that sequence number.
+static int bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n, uint32_t have_seq)
 {
     if (!b || n <= 0 || (uint32_t)n > b->bus_cap) { set_error("smx_bank_fetch: bad args"); return SMX_E_ARG; }
     SMX_HIP(hipSetDevice(b->device));
     const int bi = b->bus_cur;
-    int rv = bank_flush_fold(b);
-    if (rv) return rv;
+    const bool can_publish = publish_enabled() && (uint32_t)n <= smx_bank::PUB_MAX;
+    uint32_t seq = have_seq;
+    int rv;
+    if (!seq && can_publish && !b->comm) {
+        // a fold that the block still owes (direct form, >= 2^20 voices) is its last kernel: let it publish
+        smx::SawPublish pub;
+        pub.hbus = b->d_pub; pub.hflag = b->d_pubflag; pub.seq = b->pub_seq + 1u;
+        bool published = false;
+        rv = bank_flush_fold_pub(b, &pub, &published);
+        if (rv) return rv;
+        if (published) seq = ++b->pub_seq;
+    } else {
+        rv = bank_flush_fold(b);
+        if (rv) return rv;
+    }
     if (bank_ar_queued(b, bi)) {                   // somebody needs the sum now: issue the group
         rv = bank_comm_flush(b);
         if (rv) return rv;
@@ -835,12 +861,14 @@ extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
         b->comm_pending[bi] = false;
     }
     const int32_t *src = b->h_bus;
-    if (publish_enabled() && (uint32_t)n <= smx_bank::PUB_MAX) {
+    if (seq || can_publish) {
         // the stream's last kernel writes the bus to pinned host memory and then the sequence number: no copy
         // engine, no completion signal to wait for (22 -> 12 us per synchronous block on small banks)
-        const uint32_t seq = ++b->pub_seq;
-        rv = smx::launch_saw_publish(b->d_bus[bi], b->d_pub, b->d_pubflag, (uint32_t)n, seq, b->stream);
-        if (rv) return rv;
+        if (!seq) {
+            seq = ++b->pub_seq;
+            rv = smx::launch_saw_publish(b->d_bus[bi], b->d_pub, b->d_pubflag, (uint32_t)n, seq, b->stream);
+            if (rv) return rv;
+        }
         rv = bank_wait_published(b, seq);
         if (rv) return rv;
         src = b->h_pub;
@@ -852,6 +880,8 @@ extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n)
     if (vec) for (int i = 0; i < n; i++) vec[i] = bus_to_float(src[i]);
     return SMX_OK;
 }
+
+extern "C" int smx_bank_fetch(smx_bank *b, float *vec, int32_t *bus, int n) { return bank_fetch(b, vec, bus, n, 0); }
 
 extern "C" int smx_bank_set_block_form(smx_bank *b, int form)
 {
@@ -949,13 +979,36 @@ extern "C" int smx_bank_run(smx_bank *b, float *vec, int32_t *bus, int n)
         SMX_HIP(hipSetDevice(b->device));
         return bank_run_pipelined(b, vec, bus, n);
     }
-    int rv = smx_bank_run_async(b, n);
-    if (rv) return rv;
-    if (b->comm) {                     // a sharded bank: synth_run returns the sum over all ranks
-        rv = smx_bank_allreduce_async(b, n);
+    if (b->comm) {
+        // A sharded bank: synth_run returns the sum over all ranks.  The caller waits for this block anyway, so its
+        // sum is issued on the COMPUTE stream, right behind the kernel: no hop to the comm stream and back (two
+        // cross-stream event waits, ~10 us each on this stack: profiles/r03_bench_one_rank_communicator.json had the
+        // synchronous block at 40-47 us against 18-25 without a communicator).  Sums that earlier asynchronous
+        // blocks still have queued go first, in order (every rank does the same: the SPMD contract), and the compute
+        // stream waits for the youngest collective of the comm stream, so that two collectives of one communicator
+        // never run side by side.
+        int rv = smx_bank_run_async(b, n);
         if (rv) return rv;
+        rv = bank_flush_fold(b);
+        if (rv) return rv;
+        rv = bank_comm_flush(b);
+        if (rv) return rv;
+        if (b->last_comm_ev >= 0) SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[b->last_comm_ev], 0));
+        const int bi = b->bus_cur;
+        SMX_NCCL(ncclAllReduce(b->d_bus[bi], b->d_bus[bi], (size_t)n, ncclInt32, ncclSum, b->comm, b->stream));
+        b->ar_launches++;
+        b->ar_blocks++;
+        return smx_bank_fetch(b, vec, bus, n);
     }
-    return smx_bank_fetch(b, vec, bus, n);
+    // one rank: the block is fetched at once, so a finalize kernel that ends it may hand the bus over itself
+    smx::SawPublish pub;
+    bool published = false;
+    if (publish_enabled() && n <= 64) { pub.hbus = b->d_pub; pub.hflag = b->d_pubflag; pub.seq = b->pub_seq + 1u; }
+    int rv = bank_run_async(b, n, pub.hflag ? &pub : nullptr, &published);
+    if (rv) return rv;
+    uint32_t seq = 0;
+    if (published) seq = ++b->pub_seq;
+    return bank_fetch(b, vec, bus, n, seq);
 }
 
 extern "C" int smx_bank_run_square(smx_bank *b, float *vec, int n)
@@ -985,6 +1038,7 @@ extern "C" int smx_bank_run_square(smx_bank *b, float *vec, int n)
         SMX_HIP(hipStreamWaitEvent(b->comm_stream, b->ev_kernel[bi], 0));
         SMX_NCCL(ncclAllReduce(b->d_bus[bi], b->d_bus[bi], (size_t)n, ncclUint32, ncclMax, b->comm, b->comm_stream));
         SMX_HIP(hipEventRecord(b->ev_comm[bi], b->comm_stream));
+        b->last_comm_ev = bi;
         SMX_HIP(hipStreamWaitEvent(b->stream, b->ev_comm[bi], 0));
     }
     SMX_HIP(hipMemcpyAsync(b->h_bus, b->d_bus[bi], (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));

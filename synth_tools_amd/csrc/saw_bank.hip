@@ -119,7 +119,7 @@ constexpr size_t SAW_SCRATCH_HEADER = 64;
 // write the bus and keep the "next bus buffer is zero" contract.
 __device__ __forceinline__
 void saw_direct_fold(SawPartial *__restrict__ partial, int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
-                     uint32_t nframes, uint32_t row, uint32_t (*Ws)[64])
+                     uint32_t nframes, uint32_t row, uint32_t (*Ws)[64], smx::SawPublish pub = smx::SawPublish{})
 {
     const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
     SawPartial *p = partial + (size_t)row * SAW_SLOTS;
@@ -133,8 +133,16 @@ void saw_direct_fold(SawPartial *__restrict__ partial, int32_t *__restrict__ bus
     __syncthreads();
     const uint32_t f = row * 64u + t;
     if (part == 0 && f < nframes) {
-        bus[f] = (int32_t)(Ws[0][t] + Ws[1][t] + Ws[2][t] + Ws[3][t]);
+        const int32_t v = (int32_t)(Ws[0][t] + Ws[1][t] + Ws[2][t] + Ws[3][t]);
+        bus[f] = v;
         bus_next[f] = 0;
+        if (pub.hflag) __builtin_nontemporal_store(v, &pub.hbus[f]);
+    }
+    // a block of <= 64 frames ends here, in one wave of one workgroup: that wave hands the bus to the host itself
+    // (sums first, system-wide fence, then the sequence word: see saw_publish_kernel)
+    if (pub.hflag && part == 0) {
+        __threadfence_system();
+        if (t == 0) __hip_atomic_store(pub.hflag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -274,10 +282,10 @@ void saw_bank_kernel(const uint32_t *__restrict__ inc,
 // next launch, write the bus and keep the "next bus buffer is zero" contract.
 __global__ __launch_bounds__(256)
 void saw_direct_finalize_kernel(SawPartial *__restrict__ partial, int32_t *__restrict__ bus,
-                                int32_t *__restrict__ bus_next, uint32_t nframes)
+                                int32_t *__restrict__ bus_next, uint32_t nframes, smx::SawPublish pub)
 {
     __shared__ uint32_t Ws[4][64];
-    saw_direct_fold(partial, bus, bus_next, nframes, blockIdx.x, Ws);
+    saw_direct_fold(partial, bus, bus_next, nframes, blockIdx.x, Ws, pub);
 }
 
 // Few-frame blocks (the tick ABI: 1..4 frames) of banks with >= 2^20 voices: the same direct
@@ -866,7 +874,7 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
                               int32_t *__restrict__ bus, int32_t *__restrict__ bus_next,
                               uint32_t nframes, uint32_t nvoices, uint32_t *__restrict__ mode_flag,
                               const uint32_t *__restrict__ ran_long, uint32_t *__restrict__ host_flag,
-                              uint32_t host_tag)
+                              uint32_t host_tag, smx::SawPublish pub)
 {
     // which slot layout did this launch fill?  (written by the main kernel that ran, stable here)
     if (ran_long && *ran_long != 0u) {
@@ -931,6 +939,13 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
         if (f < nframes) {
             bus[f] = (int32_t)r;
             bus_next[f] = 0;                        // same contract as saw_bank_kernel
+            if (pub.hflag) __builtin_nontemporal_store((int32_t)r, &pub.hbus[f]);
+        }
+        // a block of <= 64 frames ends in this wave: it hands the bus to the host itself (saw_publish_kernel's
+        // protocol: sums, system-wide fence, sequence word)
+        if (pub.hflag) {
+            __threadfence_system();
+            if (t == 0) __hip_atomic_store(pub.hflag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         // Form of the next long-block launch: wrap events pay while no voice wraps more than ~6
         // times per 64 frames (inc < 6.5 * 2^26: up to MIDI note 110 at 48 kHz) and the bank's mean
@@ -1088,11 +1103,16 @@ static uint32_t grid_size(uint32_t tc, uint32_t rows, uint32_t gy)
 }
 
 // Run the fold a slot launch left behind (smx::SawPending) as a kernel of its own.
-int flush_pending(smx::SawPending *pend, hipStream_t stream)
+int flush_pending(smx::SawPending *pend, hipStream_t stream, const smx::SawPublish *pub = nullptr, bool *published = nullptr)
 {
     if (!pend || !pend->partial) return SMX_OK;
+    smx::SawPublish p{};
+    if (pub && pub->hflag && pend->nframes <= 64) {          // one workgroup ends the block: it may publish it
+        p = *pub;
+        if (published) *published = true;
+    }
     hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3((pend->nframes + 63) / 64), dim3(256), 0, stream,
-                       static_cast<SawPartial *>(pend->partial), pend->bus, pend->bus_next, pend->nframes);
+                       static_cast<SawPartial *>(pend->partial), pend->bus, pend->bus_next, pend->nframes, p);
     pend->partial = nullptr;
     SMX_HIP(hipGetLastError());
     return SMX_OK;
@@ -1138,7 +1158,7 @@ int launch_tc(const uint32_t *inc, const uint32_t *si, int32_t *bus, int32_t *bu
                 pend->region ^= 1u;
             } else {
                 hipLaunchKernelGGL(saw_direct_finalize_kernel, dim3(gy64), dim3(256), 0, stream, partial, bus,
-                                   bus_next, nframes);
+                                   bus_next, nframes, smx::SawPublish{});
             }
             SMX_HIP(hipGetLastError());
             return SMX_OK;
@@ -1188,12 +1208,15 @@ size_t saw_scratch_region_bytes(uint32_t max_frames)
 // the carry formulations use the area from the first region on, with nothing owed)
 size_t saw_scratch_bytes(uint32_t max_frames) { return SAW_SCRATCH_HEADER + 2 * saw_scratch_region_bytes(max_frames); }
 
-int launch_saw_flush(SawPending *pend, hipStream_t stream) { return flush_pending(pend, stream); }
+int launch_saw_flush(SawPending *pend, hipStream_t stream, const SawPublish *pub, bool *published)
+{
+    return flush_pending(pend, stream, pub, published);
+}
 
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
                     void *d_scratch, int long_block_form, uint32_t *host_flag, uint32_t host_tag,
-                    hipStream_t stream, SawPending *pend)
+                    hipStream_t stream, SawPending *pend, const SawPublish *pub, bool *published)
 {
     if (n_pad == 0 || (n_pad & 1023) || nframes == 0) {
         set_error("launch_saw_bank: n_pad=%u nframes=%u", n_pad, nframes);
@@ -1292,8 +1315,15 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             }
 #undef SMX_CARRY_LAUNCH
 #undef SMX_CARRY_LAUNCH_W
+            // a single 64-frame chunk ends in ONE workgroup of the finalize kernel: it may hand the bus to the host
+            SawPublish fin_pub{};
+            const bool long_layout_possible = nframes >= SAW_LONG && !no_long;
+            if (pub && pub->hflag && gy == 1 && !long_layout_possible) {
+                fin_pub = *pub;
+                if (published) *published = true;
+            }
             hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
-                               d_bus_next, nframes, n_pad, flag, ran_long, host_flag, host_tag);
+                               d_bus_next, nframes, n_pad, flag, ran_long, host_flag, host_tag, fin_pub);
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         }

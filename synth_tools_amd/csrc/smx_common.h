@@ -50,6 +50,14 @@ size_t saw_scratch_bytes(uint32_t max_frames);
 // bus -- a fetch, an all-reduce, a launch of another form -- calls launch_saw_flush first.  The stream then
 // carries one kernel per block instead of two.  Until the fold has run, `bus` holds no valid sums and
 // `bus_next` is not yet zeroed.
+// Where a block's LAST kernel may hand its bus to the host itself (round 3): device pointers of coherent pinned host
+// memory (see launch_saw_publish); hflag == nullptr: nobody asked.  Only kernels that finish a block of <= 64 frames in
+// ONE workgroup can do it (the fold of the direct form's slots, the finalize of the carry formulations).
+struct SawPublish {
+    int32_t *hbus = nullptr;
+    uint32_t *hflag = nullptr;
+    uint32_t seq = 0;
+};
 struct SawPending {
     void *partial = nullptr;            // slots of the block whose fold is owed (nullptr: nothing owed)
     int32_t *bus = nullptr, *bus_next = nullptr;
@@ -58,7 +66,8 @@ struct SawPending {
     size_t region_stride = 0;           // bytes between the two regions: saw_scratch_region_bytes(cap the scratch has)
 };
 size_t saw_scratch_region_bytes(uint32_t max_frames);
-int launch_saw_flush(SawPending *pend, hipStream_t stream);
+// pub: the fold, if one is owed and covers <= 64 frames, also publishes the bus (returns true through *published).
+int launch_saw_flush(SawPending *pend, hipStream_t stream, const SawPublish *pub = nullptr, bool *published = nullptr);
 // d_hbus / d_hflag: DEVICE pointers of coherent pinned host memory.  The kernel writes n bus words there, then seq to
 // *d_hflag (system-scope release): the host polls the flag instead of waiting for a copy and a stream.
 int launch_saw_publish(const int32_t *d_bus, int32_t *d_hbus, uint32_t *d_hflag, uint32_t n, uint32_t seq, hipStream_t stream);
@@ -72,7 +81,8 @@ int launch_saw_dropin(const uint32_t inc[64], const uint32_t state[64], int32_t 
 int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state0, int32_t *d_bus,
                     int32_t *d_bus_next, uint32_t n_pad, uint32_t nframes, uint32_t tbase,
                     void *d_scratch, int long_block_form, uint32_t *host_flag, uint32_t host_tag,
-                    hipStream_t stream, SawPending *pend = nullptr);      // pend == nullptr: every launch folds its own slots
+                    hipStream_t stream, SawPending *pend = nullptr,       // pend == nullptr: every launch folds its own slots
+                    const SawPublish *pub = nullptr, bool *published = nullptr);   // a finalize that ends the block may publish it
 // leading bytes of the scratch area that hold the formulation flag (zero: stepping form) and the bank's sum of
 // increments; after clearing them (new increments) launch_saw_sum_inc recomputes the sum
 size_t saw_scratch_header_bytes();

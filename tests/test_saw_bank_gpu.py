@@ -65,9 +65,11 @@ def test_note_on_off_over_n_voices(smx, orc):
     inc = np.zeros(n, np.uint32)
     st = np.zeros(n, np.uint32)
     rng = np.random.default_rng(11)
+    was_full = False
     for step in range(400):
         note = int(rng.integers(0, 128))
         if rng.random() < 0.75:
+            was_full = was_full or np.count_nonzero(inc) == n     # this note-on steals voice 0
             bank.note_on(note)
             orc.orc_note_on(n2v, inc, n, note)
         else:
@@ -79,7 +81,8 @@ def test_note_on_off_over_n_voices(smx, orc):
             assert np.array_equal(bus, obus)
     ginc, gst = bank.read()
     assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
-    assert np.count_nonzero(inc) == n            # the bank did fill up: stealing was exercised
+    assert was_full                              # the bank did fill up: stealing was exercised
+    # (not "is full at the end": under SMX_SOAK_SEED a stray note-off may have silenced voice 0 last)
     bank.close()
 
 
