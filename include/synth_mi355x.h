@@ -188,7 +188,8 @@ int smx_bank_comm_ranks(const smx_bank *b);
  * is needed (smx_bank_fetch / smx_bank_sync / smx_bank_run).  With a communicator
  * smx_bank_run returns the sum over all ranks in both block modes; in SMX_BLOCK_PIPELINED the
  * reduce and the copy to the host run on the second stream behind the kernel, so the caller
- * waits for neither. */
+ * waits for neither; in SMX_BLOCK_SYNC the block's sum is issued on the bank's own stream right behind
+ * its kernel (the caller waits for it anyway: no hop to the second stream and back). */
 int smx_bank_allreduce_async(smx_bank *b, int n);
 /* Blocks per collective, 1..16; default 8 (1: every block's sum is issued at once).  A group hides the
  * collective's latency L behind `blocks` kernels: it pays when blocks x (kernel time) >= L. */
