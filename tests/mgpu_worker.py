@@ -151,6 +151,23 @@ def main():
         want = np.array([orc.orc_sum_tick_square(all_inc, all_st, len(all_inc)) for _ in range(nf)], np.float32)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "square"
         res["checks"] += 1
+    # (6) synchronous blocks between asynchronous ones: the synchronous block's sum is issued on the COMPUTE stream
+    # (round 3), after the sums that earlier asynchronous blocks still have queued and after whatever the comm stream
+    # has in flight; asynchronous groups after it go back to the comm stream
+    for rnd in range(3):
+        wants = []
+        for k in range(3 + rnd):                       # queued, not yet issued (group of 8)
+            bank.run_async(64)
+            bank.allreduce_async(64)
+            wants.append(expect(64)[0])
+        bus, _ = bank.run(17 + rnd)                    # synchronous: flushes the queue first, then its own sum
+        assert np.array_equal(bus, expect(17 + rnd)[0]), ("sync after queued", rnd)
+        for k in range(9):                             # a whole group + one: the comm stream again
+            bank.run_async(64)
+            bank.allreduce_async(64)
+            want = expect(64)[0]
+        assert np.array_equal(bank.fetch(64)[0], want), ("async after sync", rnd)
+        res["checks"] += 2
     # phases of the shard after everything
     _, st = bank.read()
     assert np.array_equal(st, all_st[rank * per:(rank + 1) * per])
