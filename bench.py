@@ -561,7 +561,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
                     if not ok:
                         sys.exit("bench.py: PDM CHECK FAILED (%s, dither=%s)" % (layout, with_d))
                     checked = "pulse rows %s == closed form" % rows
-                alg = 12.0 * n + nt * n / 8.0
+                alg = 8.0 * n + nt * n / 8.0          # setpoint + lazily materialised accumulator read, pulse bits written
                 e = {"workload": "c3: carry-out PDM bank, %d channels, %d ticks/launch, %s layout, dither=%s"
                                  % (n, nt, layout, "seeded" if with_d else "0"),
                      "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",

@@ -9,6 +9,13 @@ struct smx_pdm {
     uint32_t n = 0, n_pad = 0;
     int device = 0;
     uint32_t *d_setpoint = nullptr, *d_accu = nullptr;
+    // Lazily materialised accumulators (pdm_bank.hip): accu[c] = d_accu[c] + elapsed * setpoint[c] + D, D = the sum of
+    // the dither words of the `elapsed` ticks, kept on the device in d_dsum[dsum_cur] (two words used alternately).
+    // Ticks only read; smx_pdm_read / _load / _set_setpoint materialise.
+    uint32_t elapsed = 0;
+    bool lazy = false;                           // ticks have run since the accumulators were last materialised
+    uint32_t *d_dsum = nullptr;
+    int dsum_cur = 0;
     uint32_t *d_dither = nullptr; uint32_t dither_cap = 0;
     uint32_t *d_bits = nullptr; size_t bits_cap = 0;     // bytes
     hipStream_t stream = nullptr;
@@ -34,10 +41,12 @@ extern "C" smx_pdm *smx_pdm_create(uint32_t n_channels, int device)
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipMalloc((void **)&p->d_setpoint, bytes) == hipSuccess &&
               hipMalloc((void **)&p->d_accu, bytes) == hipSuccess &&
+              hipMalloc((void **)&p->d_dsum, 8) == hipSuccess &&
               hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&p->ev_t0) == hipSuccess && hipEventCreate(&p->ev_t1) == hipSuccess &&
               hipMemsetAsync(p->d_setpoint, 0, bytes, p->stream) == hipSuccess &&
               hipMemsetAsync(p->d_accu, 0, bytes, p->stream) == hipSuccess &&
+              hipMemsetAsync(p->d_dsum, 0, 8, p->stream) == hipSuccess &&
               hipStreamSynchronize(p->stream) == hipSuccess;
     if (!ok) {
         set_error("smx_pdm_create: HIP allocation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -54,6 +63,7 @@ extern "C" void smx_pdm_destroy(smx_pdm *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->d_setpoint) (void)hipFree(p->d_setpoint);
     if (p->d_accu) (void)hipFree(p->d_accu);
+    if (p->d_dsum) (void)hipFree(p->d_dsum);
     if (p->d_dither) (void)hipFree(p->d_dither);
     if (p->d_bits) (void)hipFree(p->d_bits);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -62,10 +72,27 @@ extern "C" void smx_pdm_destroy(smx_pdm *p)
     delete p;
 }
 
+// accu0 += elapsed * setpoint + D for every channel, elapsed = 0, D = 0: the stored accumulators are current again.
+static int pdm_materialize(smx_pdm *p)
+{
+    if (!p->lazy) return SMX_OK;
+    int rv = smx::launch_pdm_materialize(p->d_setpoint, p->d_accu, p->n_pad, p->elapsed, p->d_dsum + p->dsum_cur, p->stream);
+    if (rv) return rv;
+    SMX_HIP(hipMemsetAsync(p->d_dsum, 0, 8, p->stream));
+    p->elapsed = 0;
+    p->dsum_cur = 0;
+    p->lazy = false;
+    return SMX_OK;
+}
+
 extern "C" int smx_pdm_load(smx_pdm *p, const uint32_t *setpoint, const uint32_t *accu)
 {
     if (!p) return SMX_E_ARG;
     SMX_HIP(hipSetDevice(p->device));
+    {
+        int rv = pdm_materialize(p);             // an array that is not replaced keeps its meaning
+        if (rv) return rv;
+    }
     SMX_HIP(hipStreamSynchronize(p->stream));
     if (setpoint) SMX_HIP(hipMemcpy(p->d_setpoint, setpoint, (size_t)p->n * 4, hipMemcpyHostToDevice));
     if (accu) SMX_HIP(hipMemcpy(p->d_accu, accu, (size_t)p->n * 4, hipMemcpyHostToDevice));
@@ -76,6 +103,10 @@ extern "C" int smx_pdm_read(smx_pdm *p, uint32_t *setpoint, uint32_t *accu)
 {
     if (!p) return SMX_E_ARG;
     SMX_HIP(hipSetDevice(p->device));
+    if (accu) {
+        int rv = pdm_materialize(p);
+        if (rv) return rv;
+    }
     SMX_HIP(hipStreamSynchronize(p->stream));
     if (setpoint) SMX_HIP(hipMemcpy(setpoint, p->d_setpoint, (size_t)p->n * 4, hipMemcpyDeviceToHost));
     if (accu) SMX_HIP(hipMemcpy(accu, p->d_accu, (size_t)p->n * 4, hipMemcpyDeviceToHost));
@@ -97,6 +128,10 @@ extern "C" int smx_pdm_set_setpoint(smx_pdm *p, uint32_t chan, uint32_t val)
     if (!p) return SMX_E_ARG;
     if (chan >= p->n) { set_error("smx_pdm_set_setpoint: chan %u >= %u", chan, p->n); return SMX_E_RANGE; }
     SMX_HIP(hipSetDevice(p->device));
+    {
+        int rv = pdm_materialize(p);             // the ticks run so far used the old setpoint
+        if (rv) return rv;
+    }
     const uint32_t v = pdm_safe_setpoint(val);
     SMX_HIP(hipMemcpyAsync(p->d_setpoint + chan, &v, 4, hipMemcpyHostToDevice, p->stream));
     SMX_HIP(hipStreamSynchronize(p->stream));
@@ -138,8 +173,14 @@ extern "C" int smx_pdm_tick_n_async(smx_pdm *p, uint32_t n_ticks, int with_dithe
     SMX_HIP(hipSetDevice(p->device));
     int rv = pdm_ensure(p, n_ticks);
     if (rv) return rv;
-    return smx::launch_pdm_bank(p->d_setpoint, p->d_accu, with_dither ? p->d_dither : nullptr,
-                                p->d_bits, p->n_pad, p->n, n_ticks, p->stream);
+    rv = smx::launch_pdm_bank(p->d_setpoint, p->d_accu, with_dither ? p->d_dither : nullptr,
+                              p->d_bits, p->n_pad, p->n, n_ticks, p->elapsed, p->d_dsum + p->dsum_cur,
+                              p->d_dsum + (p->dsum_cur ^ 1), p->stream);
+    if (rv) return rv;
+    p->elapsed += n_ticks;                       // mod 2^32, like the accumulators
+    p->lazy = true;
+    if (with_dither) p->dsum_cur ^= 1;
+    return SMX_OK;
 }
 
 extern "C" int smx_pdm_tick_n_streams_async(smx_pdm *p, uint32_t n_ticks, int with_dither)
@@ -150,8 +191,14 @@ extern "C" int smx_pdm_tick_n_streams_async(smx_pdm *p, uint32_t n_ticks, int wi
     SMX_HIP(hipSetDevice(p->device));
     int rv = pdm_ensure(p, n_ticks);                 // same byte count as the tick-major matrix
     if (rv) return rv;
-    return smx::launch_pdm_streams(p->d_setpoint, p->d_accu, with_dither ? p->d_dither : nullptr, p->d_bits,
-                                   p->n_pad, n_ticks, p->stream);
+    rv = smx::launch_pdm_streams(p->d_setpoint, p->d_accu, with_dither ? p->d_dither : nullptr, p->d_bits,
+                                 p->n_pad, n_ticks, p->elapsed, p->d_dsum + p->dsum_cur, p->d_dsum + (p->dsum_cur ^ 1),
+                                 p->stream);
+    if (rv) return rv;
+    p->elapsed += n_ticks;
+    p->lazy = true;
+    if (with_dither) p->dsum_cur ^= 1;
+    return SMX_OK;
 }
 
 extern "C" int smx_pdm_tick_n_streams(smx_pdm *p, uint32_t n_ticks, const uint32_t *dither, uint32_t *streams)

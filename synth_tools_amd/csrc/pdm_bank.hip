@@ -9,7 +9,13 @@
 //     out  = carry out of that add      (the pulse)
 //
 // Mapping: one lane per channel, setpoint/accu in registers for the whole run
-// of ticks (HBM: 8 B read + 4 B written per channel per launch).  The carry of
+// of ticks.  Round 3: the accumulator is kept LAZILY, like the saw bank's phase: HBM holds accu0[] as of
+// some tick, the host counts the ticks run since (T) and the device keeps the sum D of the dither words of those
+// ticks; the accumulator a launch starts from is accu0 + T*setpoint + D (mod 2^32: the modulator is linear between
+// pulses), and NOTHING is written back -- a launch reads 8 B per channel and writes its pulse bits
+// (smx_pdm_read / _load / _set_setpoint materialise: accu0 += T*setpoint + D, T = 0, D = 0).  D lives in two
+// device words used alternately (a launch with dither reads one and writes the other: late workgroups of the
+// same launch must still see the old value).  The carry of
 // a wave's 64 channels IS the compare mask of the add (an SGPR pair): the
 // 64-wide analogue of the reference's rrx shift register.  Lane t of the wave
 // keeps the mask of tick t (v_writelane), so after 64 ticks a wave holds a
@@ -100,12 +106,15 @@ struct PdmRagged<0, START, DITHER> {
 template <bool DITHER>
 __global__ __launch_bounds__(1024)
 void pdm_bank_kernel(const uint32_t *__restrict__ setpoint,
-                     uint32_t *__restrict__ accu,
+                     const uint32_t *__restrict__ accu,     // accu0[]: as of `elapsed` ticks ago
                      const uint32_t *__restrict__ dither,
                      unsigned long long *__restrict__ bits64,
                      uint32_t words64_per_tick,   // n_pad / 64
                      uint32_t nticks,
-                     uint32_t n)                  // real channels; the rest is padding
+                     uint32_t n,                  // real channels; the rest is padding
+                     uint32_t elapsed,            // ticks run since accu0 was valid
+                     const uint32_t *__restrict__ dsum_in,   // sum of the dither words of those ticks
+                     uint32_t *__restrict__ dsum_out)        // DITHER: receives dsum_in + this launch's dither words
 {
     // [buffer][tick][wave], padded.  Two buffers: tile k is written to S[k & 1], then ONE barrier,
     // then read; the buffer tile k+1 writes was last read in tile k-1, before every thread reached
@@ -115,9 +124,18 @@ void pdm_bank_kernel(const uint32_t *__restrict__ setpoint,
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t row = tid >> 4, col = tid & 15; // flush: 16 lanes x 8 B = one 128-B row
     // persistent workgroups over blocks of 1024 channels; the next block's setpoint/accu are
-    // requested before the ticks of the current one (few-tick launches of big banks are a
-    // read-modify-write stream: 64 Mi channels x 1 tick 204 -> 154 us = 5.3 TB/s)
+    // requested before the ticks of the current one (few-tick launches of big banks are a memory stream: 64 Mi
+    // channels x 1 tick 204 -> 154 us with this prefetch, 121 us since the accumulator is lazy and nothing is
+    // written back; launches of <= 8 ticks on >= 2^20 channels now take pdm_fewticks_kernel)
     const uint32_t nblocks = words64_per_tick >> 4;
+    const uint32_t dsum0 = *dsum_in;
+    if (DITHER && blockIdx.x == 0 && wave == 0) {
+        // this launch's dither words, summed by one wave, for the launches that follow (the other word of the pair)
+        uint32_t d = 0;
+        for (uint32_t t = lane; t < nticks; t += 64) d += dither[t];
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        if (lane == 0) *dsum_out = dsum0 + d;
+    }
     uint32_t sp_next = 0, a_next = 0;
     if (blockIdx.x < nblocks) {
         sp_next = setpoint[blockIdx.x * 1024u + tid];
@@ -125,9 +143,8 @@ void pdm_bank_kernel(const uint32_t *__restrict__ setpoint,
     }
     uint32_t buf = 0;
     for (uint32_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const uint32_t ch = blk * 1024u + tid;
         const uint32_t sp = sp_next;
-        uint32_t a = a_next;
+        uint32_t a = a_next + elapsed * sp + dsum0;          // the accumulator as of now (lazy: see the header)
         const uint32_t nb = min(blk + gridDim.x, nblocks - 1) * 1024u + tid;   // last trip re-reads its own
         sp_next = setpoint[nb];
         a_next = accu[nb];
@@ -147,7 +164,57 @@ void pdm_bank_kernel(const uint32_t *__restrict__ setpoint,
                 bits64[(size_t)(t0 + row) * words64_per_tick + blk * 16u + col] = S[buf][row][col] & vmask;
             buf ^= 1;
         }
-        accu[ch] = a;
+    }
+}
+
+// One or two ticks per launch (the tick ABI) on a big bank: with the lazy accumulator the launch is a pure READ stream
+// of 8 B per channel, and the 1024-thread tile machinery above (64-tick tiles, LDS transpose, a barrier per 1024
+// channels) is in its way.  Here: one lane per channel, four 64-channel words per wave and trip (eight 4-byte loads in
+// flight per lane), the wave's carry-outs of a tick are the compare mask of the add (__ballot: the rrx register, 64
+// wide), and lane 0 stores it as one 64-bit word of the tick-major matrix.
+template <bool DITHER>
+__global__ __launch_bounds__(256)
+void pdm_fewticks_kernel(const uint32_t *__restrict__ setpoint, const uint32_t *__restrict__ accu,
+                         const uint32_t *__restrict__ dither, unsigned long long *__restrict__ bits64,
+                         uint32_t words64_per_tick, uint32_t nticks /* <= 8 */, uint32_t n, uint32_t elapsed,
+                         const uint32_t *__restrict__ dsum_in, uint32_t *__restrict__ dsum_out)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t dsum0 = *dsum_in;
+    uint32_t d[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) d[t] = (DITHER && (uint32_t)t < nticks) ? dither[t] : 0u;     // wave-uniform
+    if (DITHER && blockIdx.x == 0 && tid == 0) {
+        uint32_t sum = dsum0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) sum += d[t];             // words beyond nticks are 0
+        *dsum_out = sum;
+    }
+    const uint32_t gw = blockIdx.x * 4u + (tid >> 6), nwaves = gridDim.x * 4u;
+    for (uint32_t w0 = gw * 4u; w0 < words64_per_tick; w0 += nwaves * 4u) {
+        uint32_t sp[4], a[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                       // words64_per_tick is a multiple of 16: w0 + k is in range
+            const uint32_t ch = (w0 + k) * 64u + lane;
+            sp[k] = __builtin_nontemporal_load(setpoint + ch);
+            a[k] = __builtin_nontemporal_load(accu + ch);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t base = (w0 + k) * 64u;
+            // padding channels (setpoint 0) would still pulse under dither: masked beyond the last real channel
+            const unsigned long long vmask = base + 64u <= n ? ~0ull : (base < n ? (1ull << (n - base)) - 1ull : 0ull);
+            uint32_t acc = a[k] + elapsed * sp[k] + dsum0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {                                  // (static indices: d[] stays in registers)
+                if ((uint32_t)t < nticks) {                                // wave-uniform
+                    const uint32_t x = sp[k] + d[t];
+                    acc += x;
+                    const unsigned long long m = __ballot(acc < x);       // carry out of accu += x
+                    if (lane == 0) bits64[(size_t)t * words64_per_tick + w0 + k] = m & vmask;
+                }
+            }
+        }
     }
 }
 
@@ -184,14 +251,22 @@ __device__ __forceinline__ void stream_step4(u32x4 &a, const u32x4 &x, u32x4 &w)
 
 template <bool DITHER>
 __global__ __launch_bounds__(256)
-void pdm_stream_kernel(const uint32_t *__restrict__ setpoint, uint32_t *__restrict__ accu,
+void pdm_stream_kernel(const uint32_t *__restrict__ setpoint, const uint32_t *__restrict__ accu,
                        const uint32_t *__restrict__ dither, uint32_t *__restrict__ streams,
-                       uint32_t ngroups /* n_pad / 4 */, uint32_t nwords /* nticks / 32 */)
+                       uint32_t ngroups /* n_pad / 4 */, uint32_t nwords /* nticks / 32 */,
+                       uint32_t elapsed, const uint32_t *__restrict__ dsum_in, uint32_t *__restrict__ dsum_out)
 {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t dsum0 = *dsum_in;
+    if (DITHER && blockIdx.x == 0 && threadIdx.x < 64) {
+        uint32_t d = 0;
+        for (uint32_t t = threadIdx.x; t < nwords * 32u; t += 64) d += dither[t];
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        if (threadIdx.x == 0) *dsum_out = dsum0 + d;
+    }
     if (g >= ngroups) return;
     const u32x4 sp = reinterpret_cast<const u32x4 *>(setpoint)[g];
-    u32x4 a = reinterpret_cast<const u32x4 *>(accu)[g];
+    u32x4 a = reinterpret_cast<const u32x4 *>(accu)[g] + elapsed * sp + dsum0;
     for (uint32_t k = 0; k < nwords; k++) {
         u32x4 w = 0;
 #pragma unroll
@@ -204,15 +279,35 @@ void pdm_stream_kernel(const uint32_t *__restrict__ setpoint, uint32_t *__restri
         o.x = __brev(w.x); o.y = __brev(w.y); o.z = __brev(w.z); o.w = __brev(w.w);
         reinterpret_cast<u32x4 *>(streams)[(size_t)k * ngroups + g] = o;
     }
-    reinterpret_cast<u32x4 *>(accu)[g] = a;
+}
+
+// accu0 += elapsed * setpoint + D: the stored accumulators are current again (the host then resets elapsed and D).
+__global__ __launch_bounds__(256)
+void pdm_materialize_kernel(const uint32_t *__restrict__ setpoint, uint32_t *__restrict__ accu, uint32_t n_pad,
+                            uint32_t elapsed, const uint32_t *__restrict__ dsum_in)
+{
+    const uint32_t dsum0 = *dsum_in;
+    for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < n_pad; c += gridDim.x * 256u)
+        accu[c] += elapsed * setpoint[c] + dsum0;
 }
 
 }  // namespace
 
 namespace smx {
 
-int launch_pdm_streams(const uint32_t *d_setpoint, uint32_t *d_accu, const uint32_t *d_dither,
-                       uint32_t *d_streams, uint32_t n_pad, uint32_t nticks, hipStream_t stream)
+int launch_pdm_materialize(const uint32_t *d_setpoint, uint32_t *d_accu, uint32_t n_pad, uint32_t elapsed,
+                           const uint32_t *d_dsum_in, hipStream_t stream)
+{
+    uint32_t gx = n_pad / 256;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(pdm_materialize_kernel, dim3(gx), dim3(256), 0, stream, d_setpoint, d_accu, n_pad, elapsed, d_dsum_in);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_pdm_streams(const uint32_t *d_setpoint, const uint32_t *d_accu, const uint32_t *d_dither,
+                       uint32_t *d_streams, uint32_t n_pad, uint32_t nticks, uint32_t elapsed,
+                       const uint32_t *d_dsum_in, uint32_t *d_dsum_out, hipStream_t stream)
 {
     if (n_pad == 0 || (n_pad & 1023) || (nticks & 31)) {
         set_error("launch_pdm_streams: n_pad=%u nticks=%u (multiple of 32)", n_pad, nticks);
@@ -223,24 +318,45 @@ int launch_pdm_streams(const uint32_t *d_setpoint, uint32_t *d_accu, const uint3
     const dim3 grid((ngroups + 255) / 256), block(256);
     if (d_dither)
         hipLaunchKernelGGL(pdm_stream_kernel<true>, grid, block, 0, stream, d_setpoint, d_accu, d_dither,
-                           d_streams, ngroups, nticks / 32);
+                           d_streams, ngroups, nticks / 32, elapsed, d_dsum_in, d_dsum_out);
     else
         hipLaunchKernelGGL(pdm_stream_kernel<false>, grid, block, 0, stream, d_setpoint, d_accu, d_dither,
-                           d_streams, ngroups, nticks / 32);
+                           d_streams, ngroups, nticks / 32, elapsed, d_dsum_in, d_dsum_out);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
 
 
-int launch_pdm_bank(const uint32_t *d_setpoint, uint32_t *d_accu,
+int launch_pdm_bank(const uint32_t *d_setpoint, const uint32_t *d_accu,
                     const uint32_t *d_dither, uint32_t *d_bits, uint32_t n_pad,
-                    uint32_t n, uint32_t nticks, hipStream_t stream)
+                    uint32_t n, uint32_t nticks, uint32_t elapsed, const uint32_t *d_dsum_in, uint32_t *d_dsum_out,
+                    hipStream_t stream)
 {
     if (n_pad == 0 || (n_pad & 1023) || n > n_pad) {
         set_error("launch_pdm_bank: n_pad=%u n=%u", n_pad, n);
         return SMX_E_ARG;
     }
     if (nticks == 0) return SMX_OK;
+    static const bool no_few = getenv("SMX_PDM_NO_FEWTICKS") != nullptr;          // A/B switch
+    static const char *fmax = getenv("SMX_PDM_FEWTICKS_MAX");                     // tuning override (1..8)
+    // (64 Mi channels: 1 tick 86.7 us against 121 us for the tile kernel, 2 ticks 117.8 against 128.6; 4 ticks 173 against
+    // 137, 8 ticks 272 against 142: a 64-bit store per wave and tick does not scale -- profiles/r03_pdm_few_sweep.txt)
+    const uint32_t few_max = fmax ? (uint32_t)atoi(fmax) : 2u;
+    if (nticks <= few_max && nticks <= 8 && n_pad >= (1u << 20) && !no_few) {
+        // the tick ABI on a big bank: a read stream (pdm_fewticks_kernel)
+        auto *b64f = reinterpret_cast<unsigned long long *>(d_bits);
+        const uint32_t w64 = n_pad / 64;
+        uint32_t gx = w64 / 16;                              // one trip of 4 waves x 4 words per workgroup at least
+        if (gx > 2048) gx = 2048;
+        if (d_dither)
+            hipLaunchKernelGGL(pdm_fewticks_kernel<true>, dim3(gx), dim3(256), 0, stream, d_setpoint, d_accu, d_dither,
+                               b64f, w64, nticks, n, elapsed, d_dsum_in, d_dsum_out);
+        else
+            hipLaunchKernelGGL(pdm_fewticks_kernel<false>, dim3(gx), dim3(256), 0, stream, d_setpoint, d_accu, d_dither,
+                               b64f, w64, nticks, n, elapsed, d_dsum_in, d_dsum_out);
+        SMX_HIP(hipGetLastError());
+        return SMX_OK;
+    }
     // persistent workgroups (2 x 1024 threads are resident per CU; 1024 measured best: 512 loses 6 % on
     // 1 Mi channels x 4096 ticks, 256 loses 25 %)
     static const char *env = getenv("SMX_PDM_GRID");                    // tuning override
@@ -251,10 +367,10 @@ int launch_pdm_bank(const uint32_t *d_setpoint, uint32_t *d_accu,
     auto *b64 = reinterpret_cast<unsigned long long *>(d_bits);
     if (d_dither)
         hipLaunchKernelGGL(pdm_bank_kernel<true>, grid, block, 0, stream, d_setpoint, d_accu,
-                           d_dither, b64, n_pad / 64, nticks, n);
+                           d_dither, b64, n_pad / 64, nticks, n, elapsed, d_dsum_in, d_dsum_out);
     else
         hipLaunchKernelGGL(pdm_bank_kernel<false>, grid, block, 0, stream, d_setpoint, d_accu,
-                           d_dither, b64, n_pad / 64, nticks, n);
+                           d_dither, b64, n_pad / 64, nticks, n, elapsed, d_dsum_in, d_dsum_out);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

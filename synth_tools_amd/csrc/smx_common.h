@@ -99,13 +99,21 @@ int launch_saw_rebase_batch(uint32_t *d_inc, uint32_t *d_state0, const uint32_t 
 int launch_saw_materialize(const uint32_t *d_inc, uint32_t *d_state0, uint32_t n_pad, uint32_t tbase,
                            hipStream_t stream);
 // Carry-out PDM bank (pdm_bank.hip).  n_pad multiple of 1024; d_bits rows are n_pad/8 bytes.
-int launch_pdm_bank(const uint32_t *d_setpoint, uint32_t *d_accu,
+// The accumulators are lazy: d_accu holds accu0[] as of `elapsed` ticks ago, *d_dsum_in the sum of the dither words of
+// those ticks; a launch reads both and writes nothing back.  With dither it leaves *d_dsum_in + (its own dither
+// words' sum) in *d_dsum_out (the other word of a pair: late workgroups still read the old one).
+int launch_pdm_bank(const uint32_t *d_setpoint, const uint32_t *d_accu,
                     const uint32_t *d_dither /*nullable*/, uint32_t *d_bits,
-                    uint32_t n_pad, uint32_t n, uint32_t nticks, hipStream_t stream);
+                    uint32_t n_pad, uint32_t n, uint32_t nticks, uint32_t elapsed,
+                    const uint32_t *d_dsum_in, uint32_t *d_dsum_out, hipStream_t stream);
 
 // Same ticks, channel-stream output: d_streams[nticks/32][n_pad] (bit j = tick 32k+j).
-int launch_pdm_streams(const uint32_t *d_setpoint, uint32_t *d_accu, const uint32_t *d_dither,
-                       uint32_t *d_streams, uint32_t n_pad, uint32_t nticks, hipStream_t stream);
+int launch_pdm_streams(const uint32_t *d_setpoint, const uint32_t *d_accu, const uint32_t *d_dither,
+                       uint32_t *d_streams, uint32_t n_pad, uint32_t nticks, uint32_t elapsed,
+                       const uint32_t *d_dsum_in, uint32_t *d_dsum_out, hipStream_t stream);
+// accu0 += elapsed * setpoint + *d_dsum_in for every channel (the caller then resets elapsed and the dither sums)
+int launch_pdm_materialize(const uint32_t *d_setpoint, uint32_t *d_accu, uint32_t n_pad, uint32_t elapsed,
+                           const uint32_t *d_dsum_in, hipStream_t stream);
 
 // Poly voice bank (poly_bank.hip): device SoA arrays, n_pad entries each.
 struct PolyArrays {

@@ -44,6 +44,22 @@ def main():
         assert np.array_equal(vec, gold[name + "_vec_bits"]), name
         assert np.array_equal(st, gold[name + "_state"]) and np.array_equal(inc, gold[name + "_inc"]), name
         checks += 1
+    # the PDM bank in the tick regime on a big bank (<= 8 ticks per launch: the few-ticks read-stream kernel;
+    # SMX_PDM_NO_FEWTICKS: the tile kernel), with and without dither, the lazily kept accumulators read back in between
+    nch = (1 << 20) + 1024 + 37
+    sp, ac = synthetic.pdm_bank(nch, 0x5EED0E03)
+    ac = (synthetic.splitmix64(9, nch) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    pdm = sta.PdmBank(nch)
+    pdm.load(sp, ac)
+    oac = ac.copy()
+    for k, nt in enumerate((1, 3, 8, 64, 1, 5, 2, 100, 7)):
+        dith = synthetic.dither_stream(nt, 40 + k, 0x0FFFFFFF) if k % 2 else None
+        bits = pdm.tick_n(nt, dith)
+        assert np.array_equal(bits, oracle.pdm_run(orc, sp, oac, nt, dith)), ("pdm", k, nt)
+        if k in (2, 5, 8):
+            assert np.array_equal(pdm.read()[1], oac), ("pdm accu", k)
+        checks += 1
+    pdm.close()
     # the poly bank: un-fetched blocks, then a fetched one (the fold deferred to the next launch; SMX_POLY_NO_DEFER:
     # every launch folds its own copies)
     import ctypes as C
