@@ -54,7 +54,7 @@ ISSUE = {"saw_direct": 2.66 + 2.85 + 2.85,            # v_ashrrev + v_add (phase
          "dither_add": 2.85,
          "pwm2": 2.48 + 2.66 + 2.85 + 2 * 4.72 + 0.75 * 4.28,   # and, sub, add, 2 add3, 3 v_perm per 4 channel-ticks
          "poly": None}                                # mixed int / fp32 / LDS: see the counters in profiles/
-ALL_LEGS = ("saw_frames", "saw_hi", "c2", "c5", "c3", "c3_streams", "pwm", "c4")
+ALL_LEGS = ("saw_frames", "saw_hi", "c2", "c5", "c3", "c3_streams", "pdm_tick", "pwm", "c4")
 
 
 def parse():
@@ -571,6 +571,40 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
                      "verified": checked}
                 e["hbm_frac"] = e["roofline"]["hbm_frac"]
                 out.append(e)
+        p.close()
+    if "pdm_tick" in legs:
+        # the carry-out PDM bank in the regime the %HBM metric is defined in: the tick ABI (one ISR tick per launch,
+        # mod_pdm.c:177-194) on a bank that streams from HBM -- 64 Mi channels, 8 B read per channel (setpoint + the
+        # lazily materialised accumulator) + 1 bit written
+        n = 1 << 26
+        sp, ac = synthetic.pdm_bank(n, 0x5EED0013)
+        ac = (synthetic.splitmix64(0x5EED0014, n) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        p = sta.PdmBank(n)
+        p.load(sp, ac)
+        timed = {}
+        for nt in (1, 2):
+            settle(lambda: p.tick_n_async(nt, False), p.sync)
+            p.timer_start()
+            reps = 100
+            for _ in range(reps):
+                p.tick_n_async(nt, False)
+            timed[nt] = p.timer_stop() / reps
+        for nt in (1, 2):
+            ms = timed[nt]
+            checked = None
+            if verify:
+                _, a0 = p.read()
+                got = p.tick_n(nt)
+                want = pdm_rows_closed_form(sp, a0, None, list(range(nt)))
+                if not all(np.array_equal(got[t], w) for t, w in zip(range(nt), want)):
+                    sys.exit("bench.py: PDM CHECK FAILED (tick ABI, %d tick(s))" % nt)
+                checked = "all %d pulse row(s) == closed form" % nt
+            alg = 8.0 * n + nt * n / 8.0
+            e = {"workload": "carry-out PDM bank, %d channels, %d tick(s)/launch (tick ABI), dither=0" % (n, nt),
+                 "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
+                 "ms_per_step": round(ms, 5), "roofline": roof(alg, ms), "verified": checked}
+            e["hbm_frac"] = e["roofline"]["hbm_frac"]
+            out.append(e)
         p.close()
     if "pwm" in legs:
         # noise-shaped PWM bank (mod_pdm_pwm.c: pdm2 + glide + control rate), 1 Mi channels
