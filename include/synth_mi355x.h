@@ -222,6 +222,9 @@ int smx_pdm_init(smx_pdm *p);
 /* mod_synth.c:104-111 (SETPOINT): -2 if chan out of range. */
 int smx_pdm_set_setpoint(smx_pdm *p, uint32_t chan, uint32_t val);
 uint32_t pdm_safe_setpoint(uint32_t setpoint);       /* mod_pdm.c:101-107 */
+/* (The accumulators are kept lazily on the device -- accu0 + ticks * setpoint + the sum of the ticks' dither words,
+ * mod 2^32: the modulator is linear between pulses -- so a tick launch only reads; smx_pdm_load, smx_pdm_read(accu)
+ * and smx_pdm_set_setpoint first bring the stored accumulators up to date, one pass over the bank.) */
 int smx_pdm_load(smx_pdm *p, const uint32_t *setpoint, const uint32_t *accu);
 int smx_pdm_read(smx_pdm *p, uint32_t *setpoint, uint32_t *accu);
 /* n_ticks of the PDM ISR body (mod_pdm.c:259-264).  dither: host
