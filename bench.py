@@ -54,7 +54,7 @@ ISSUE = {"saw_direct": 2.66 + 2.85 + 2.85,            # v_ashrrev + v_add (phase
          "dither_add": 2.85,
          "pwm2": 2.48 + 2.66 + 2.85 + 2 * 4.72 + 0.75 * 4.28,   # and, sub, add, 2 add3, 3 v_perm per 4 channel-ticks
          "poly": None}                                # mixed int / fp32 / LDS: see the counters in profiles/
-ALL_LEGS = ("saw_frames", "saw_hi", "c2", "c5", "c3", "c3_streams", "pdm_tick", "pwm", "c4")
+ALL_LEGS = ("saw_frames", "saw_hi", "c2", "c5", "c3", "c3_streams", "pwm", "c4", "pdm_tick")
 
 
 def parse():
@@ -418,10 +418,7 @@ def time_saw(saw, frames, steps, warmup, comm=False, settle_ms=30.0):
         if comm:
             bank.allreduce_async(frames)
     bank.sync()
-    while (time.perf_counter() - t0) * 1e3 < settle_ms:
-        for _ in range(max(1, warmup)):
-            saw.run_async(frames)
-        bank.sync()
+    settle(lambda: saw.run_async(frames), bank.sync, ms=max(0.0, settle_ms - (time.perf_counter() - t0) * 1e3))
     bank.timer_start()
     for _ in range(steps):
         saw.run_async(frames)
@@ -432,14 +429,27 @@ def time_saw(saw, frames, steps, warmup, comm=False, settle_ms=30.0):
     return ms / steps
 
 
-def settle(step, sync, ms=30.0):
-    """Untimed steps until `ms` have passed (see time_saw): clock ramp after an idle gap."""
+def settle(step, sync, ms=30.0, cap_ms=600.0):
+    """Untimed steps until the launch time has settled: at least `ms` (clock ramp after an idle gap: time_saw) AND
+    until two consecutive batches of steps take the same time within 4 %.  The second condition is there because a
+    large device-to-host read-back (a leg's check of a 64 Mi-element bank) leaves the NEXT launches several times
+    slower for tens of milliseconds -- longer than any fixed pause we tried (measured: the first 20 launches of a
+    1 Mi-channel PWM block 0.83 ms each after such a read, 0.21 ms from then on; tools/README.md).  Bounded by cap_ms."""
     t0 = time.perf_counter()
+    last = None
     while True:
-        step()
+        b0 = time.perf_counter()
+        for _ in range(8):
+            step()
         sync()
-        if (time.perf_counter() - t0) * 1e3 >= ms:
+        now = time.perf_counter()
+        batch = now - b0
+        spent = (now - t0) * 1e3
+        if spent >= cap_ms:
             return
+        if spent >= ms and last is not None and abs(batch - last) <= 0.04 * max(batch, last):
+            return
+        last = batch
 
 
 def saw_entry(workload, voices, frames, ms, issue, extra=None):
@@ -572,40 +582,6 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
                 e["hbm_frac"] = e["roofline"]["hbm_frac"]
                 out.append(e)
         p.close()
-    if "pdm_tick" in legs:
-        # the carry-out PDM bank in the regime the %HBM metric is defined in: the tick ABI (one ISR tick per launch,
-        # mod_pdm.c:177-194) on a bank that streams from HBM -- 64 Mi channels, 8 B read per channel (setpoint + the
-        # lazily materialised accumulator) + 1 bit written
-        n = 1 << 26
-        sp, ac = synthetic.pdm_bank(n, 0x5EED0013)
-        ac = (synthetic.splitmix64(0x5EED0014, n) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        p = sta.PdmBank(n)
-        p.load(sp, ac)
-        timed = {}
-        for nt in (1, 2):
-            settle(lambda: p.tick_n_async(nt, False), p.sync)
-            p.timer_start()
-            reps = 100
-            for _ in range(reps):
-                p.tick_n_async(nt, False)
-            timed[nt] = p.timer_stop() / reps
-        for nt in (1, 2):
-            ms = timed[nt]
-            checked = None
-            if verify:
-                _, a0 = p.read()
-                got = p.tick_n(nt)
-                want = pdm_rows_closed_form(sp, a0, None, list(range(nt)))
-                if not all(np.array_equal(got[t], w) for t, w in zip(range(nt), want)):
-                    sys.exit("bench.py: PDM CHECK FAILED (tick ABI, %d tick(s))" % nt)
-                checked = "all %d pulse row(s) == closed form" % nt
-            alg = 8.0 * n + nt * n / 8.0
-            e = {"workload": "carry-out PDM bank, %d channels, %d tick(s)/launch (tick ABI), dither=0" % (n, nt),
-                 "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
-                 "ms_per_step": round(ms, 5), "roofline": roof(alg, ms), "verified": checked}
-            e["hbm_frac"] = e["roofline"]["hbm_frac"]
-            out.append(e)
-        p.close()
     if "pwm" in legs:
         # noise-shaped PWM bank (mod_pdm_pwm.c: pdm2 + glide + control rate), 1 Mi channels
         n, nt = 1 << 20, 1024
@@ -713,6 +689,45 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
                                       "per voice-sample at 5.1 cycles each, 3.9 with 8 waves per SIMD) on top of a 4.4 us one-frame "
                                       "launch; DESIGN 3.5")
             out.append(e)
+    # (last: a bank of this size leaves the allocator's free space in pieces when it goes -- see the note in the leg)
+    if "pdm_tick" in legs:
+        # the carry-out PDM bank in the regime the %HBM metric is defined in: the tick ABI (one ISR tick per launch,
+        # mod_pdm.c:177-194) on a bank that streams from HBM -- 64 Mi channels, 8 B read per channel (setpoint + the
+        # lazily materialised accumulator) + 1 bit written
+        n = 1 << 26
+        sp, ac = synthetic.pdm_bank(n, 0x5EED0013)
+        ac = (synthetic.splitmix64(0x5EED0014, n) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        p = sta.PdmBank(n)
+        p.load(sp, ac)
+        timed = {}
+        for nt in (1, 2):
+            settle(lambda: p.tick_n_async(nt, False), p.sync)
+            p.timer_start()
+            reps = 100
+            for _ in range(reps):
+                p.tick_n_async(nt, False)
+            timed[nt] = p.timer_stop() / reps
+        for nt in (1, 2):
+            ms = timed[nt]
+            checked = None
+            if verify:
+                _, a0 = p.read()
+                got = p.tick_n(nt)
+                want = pdm_rows_closed_form(sp, a0, None, list(range(nt)))
+                if not all(np.array_equal(got[t], w) for t, w in zip(range(nt), want)):
+                    sys.exit("bench.py: PDM CHECK FAILED (tick ABI, %d tick(s))" % nt)
+                checked = "all %d pulse row(s) == closed form" % nt
+            alg = 8.0 * n + nt * n / 8.0
+            e = {"workload": "carry-out PDM bank, %d channels, %d tick(s)/launch (tick ABI), dither=0" % (n, nt),
+                 "value": round(n * nt / (ms * 1e-3) / 1e9, 2), "unit": "Gsamples/s (channel-ticks)",
+                 "ms_per_step": round(ms, 5), "roofline": roof(alg, ms), "verified": checked}
+            e["hbm_frac"] = e["roofline"]["hbm_frac"]
+            out.append(e)
+        p.close()
+        # Order matters for what FOLLOWS a leg like this one: after its 0.5 GB arrays and their read-backs are gone,
+        # the 1 GiB duty buffer of the PWM leg came to lie in recycled memory and its tick-major rows (1 MB apart, 1024
+        # of them written side by side) ran at 0.82 ms instead of 0.21 ms per launch, steadily -- not a transient that
+        # settling cures.  So this leg runs after the others.
     return out
 
 

@@ -106,6 +106,7 @@ struct smx_bank {
     // Lazily materialised phases (saw_bank.hip): phase[v] = d_state0[v] + elapsed * d_inc[v].
     // Blocks only read; the host adds the block length to `elapsed`.
     uint32_t *d_state0 = nullptr;
+    bool one_alloc = false;                      // d_state0 lies in d_inc's allocation (the default)
     uint32_t elapsed = 0;
     // A ring of bus buffers: [cur] holds the last block (and may be feeding an all-reduce),
     // [cur+1] was zeroed by the last launch for the next one, [cur+2] is the one the next
@@ -303,8 +304,22 @@ extern "C" smx_bank *smx_bank_create(uint32_t n_voices, int device)
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     const size_t bytes = (size_t)b->n_pad * 4;
-    if ((e = hipMalloc((void **)&b->d_inc, bytes)) != hipSuccess) return fail("hipMalloc inc", e);
-    if ((e = hipMalloc((void **)&b->d_state0, bytes)) != hipSuccess) return fail("hipMalloc state", e);
+    {
+        // Both arrays in ONE allocation, state0[] right behind inc[] (round 3).  The HBM-bound tick step is bimodal by
+        // PROCESS with two allocations -- 76 us or 82 us on 64 Mi voices, depending on where the second one lands
+        // relative to the first (round 2: "1 bank in 8 at 81 us"; round 3: three processes in a row at 82.4 us on one
+        // box, then 76.2 in the next) -- and was 76.2-76.8 us in ten processes out of ten with one allocation, against
+        // 76.2-77.7 with two on the same box (profiles/r03_one_alloc.txt).  SMX_BANK_TWO_ALLOCS=1: as before.
+        static const bool two = getenv("SMX_BANK_TWO_ALLOCS") != nullptr;
+        if (!two) {
+            if ((e = hipMalloc((void **)&b->d_inc, 2 * bytes)) != hipSuccess) return fail("hipMalloc inc+state", e);
+            b->d_state0 = b->d_inc + b->n_pad;
+            b->one_alloc = true;
+        } else {
+            if ((e = hipMalloc((void **)&b->d_inc, bytes)) != hipSuccess) return fail("hipMalloc inc", e);
+            if ((e = hipMalloc((void **)&b->d_state0, bytes)) != hipSuccess) return fail("hipMalloc state", e);
+        }
+    }
     if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
     if ((e = hipHostMalloc((void **)&b->h_form, 64, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
     b->h_form[0] = 0xFFFFFFFFu;
@@ -338,7 +353,7 @@ extern "C" void smx_bank_destroy(smx_bank *b)
     if (b->comm_stream) (void)hipStreamSynchronize(b->comm_stream);
     if (b->comm) (void)ncclCommDestroy(b->comm);
     if (b->d_inc) (void)hipFree(b->d_inc);
-    if (b->d_state0) (void)hipFree(b->d_state0);
+    if (b->d_state0 && !b->one_alloc) (void)hipFree(b->d_state0);
     if (b->d_ring) (void)hipFree(b->d_ring);
     for (int i = 0; i < smx_bank::NBUS; i++) {
         if (b->ev_kernel[i]) (void)hipEventDestroy(b->ev_kernel[i]);
