@@ -293,6 +293,16 @@ class SawBank:
         _check(lib().smx_bank_run(self._h, _ptr(vec), _ptr(bus), n), "smx_bank_run")
         return bus, vec
 
+    def load_run(self, inc, state, n):
+        """smx_bank_load_run: new increments and phases, then synth_run for n frames, one synchronisation."""
+        inc = np.ascontiguousarray(inc, np.uint32)
+        state = np.ascontiguousarray(state, np.uint32)
+        assert inc.shape == (self.n,) and state.shape == (self.n,)
+        vec = np.empty(n, np.float32)
+        bus = np.empty(n, np.int32)
+        _check(lib().smx_bank_load_run(self._h, _ptr(inc), _ptr(state), _ptr(vec), _ptr(bus), n), "smx_bank_load_run")
+        return bus, vec
+
     def run_square(self, n):
         vec = np.empty(n, np.float32)
         _check(lib().smx_bank_run_square(self._h, _ptr(vec), n), "smx_bank_run_square")

@@ -486,13 +486,25 @@ extern "C" int smx_bank_load_run(smx_bank *b, const uint32_t *inc, const uint32_
                                  int32_t *bus, int n)
 {
     if (!b || !inc || !state || n <= 0) { set_error("smx_bank_load_run: bad args"); return SMX_E_ARG; }
+    if (b->shard_total) { set_error("smx_bank_load_run: a sharded bank loads collectively (smx_bank_load)"); return SMX_E_STATE; }
     SMX_HIP(hipSetDevice(b->device));
+    {
+        int rv = bank_flush_fold(b);         // an owed fold belongs to the block before the new arrays
+        if (rv) return rv;
+    }
     // pageable sources: hipMemcpyAsync stages them before returning, so the caller's arrays may
     // change right after the call; both copies and the kernel are ordered on the bank's stream
     SMX_HIP(hipMemcpyAsync(b->d_inc, inc, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
     SMX_HIP(hipMemcpyAsync(b->d_state0, state, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
     b->elapsed = 0;
     b->free_map.load(inc, b->n);
+    if (b->d_scratch) {
+        // as in smx_bank_load: the long-block forms take the bank's sum of increments from the scratch header
+        SMX_HIP(hipMemsetAsync(b->d_scratch, 0, smx::saw_scratch_header_bytes(), b->stream));
+        int rv = smx::launch_saw_sum_inc(b->d_inc, b->n_pad, b->d_scratch, b->stream);
+        if (rv) return rv;
+    }
+    bank_form_unpin(b);
     return smx_bank_run(b, vec, bus, n);
 }
 

@@ -692,3 +692,37 @@ def test_long_block_sequences_with_a_pinned_form(smx, orc, inc_table, form):
     ginc, gst = bank.read()
     assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
     bank.close()
+
+
+@pytest.mark.parametrize("n", [64, 5000, 1 << 17, (1 << 20) + 4096, 1 << 23])
+def test_load_run_replaces_both_arrays_on_any_bank(smx, orc, inc_table, n):
+    """smx_bank_load_run (new increments + phases + one block, one synchronisation) on banks of every launch class:
+    long blocks of >= 2^23-voice banks (the carry formulations) take the bank's sum of increments from the scratch
+    header, which the call has to bring up to date like smx_bank_load does; between the calls ordinary blocks, an un-fetched block whose
+    slot fold is still owed, and a bank that had pinned a form."""
+    bank = smx.SawBank(n)
+    rng = np.random.default_rng(n)
+    inc0, st0 = synthetic.saw_bank(n, 0x5EED0A00, inc_table, active_fraction=0.8)
+    bank.load(inc0, st0)
+    for _ in range(6):
+        bank.run_async(64)                                     # AUTO may pin a form on the old increments
+    st = None
+    for k, nf in enumerate([64, 1, 128, 64, 33, 256, 64]):
+        inc, st = synthetic.saw_bank(n, 0x5EED0A01 + k, inc_table, active_fraction=0.3 + 0.1 * k)
+        if k == 3:
+            inc = np.where(rng.random(n) < 0.5, inc, np.uint32(0xF0000001)).astype(np.uint32)   # far above the event form's bound
+        bus, vec = bank.load_run(inc, st, nf)
+        pick = sorted({0, nf // 2, nf - 1})
+        assert np.array_equal(bus[pick], _bus_at(inc, st, pick)), (n, k, nf)
+        if n <= (1 << 17):
+            obus, ovec = oracle.synth_run(orc, inc, st.copy(), nf)
+            assert np.array_equal(bus, obus) and np.array_equal(vec.view(np.uint32), ovec.view(np.uint32))
+        with np.errstate(over="ignore"):
+            st = st + np.uint32(nf) * inc
+        nf2 = [64, 16, 1][k % 3]
+        bank.run_async(nf2)                                    # left un-fetched: the next load_run meets its owed fold
+        with np.errstate(over="ignore"):
+            st = st + np.uint32(nf2) * inc
+    ginc, gst = bank.read()
+    assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+    bank.close()
