@@ -41,6 +41,7 @@ extern "C" {
 
 const char *smx_last_error(void);
 int  smx_device_count(void);             /* 0 when no GPU is visible      */
+#define SMX_VERSION 1                    /* of this header; smx_version() = the library's */
 int  smx_version(void);
 int  smx_device_synchronize(int device); /* all streams of the device idle */
 

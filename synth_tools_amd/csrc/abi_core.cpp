@@ -60,7 +60,7 @@ extern "C" phasor_t note_to_inc(int note)
 // misc
 // ---------------------------------------------------------------------------
 extern "C" const char *smx_last_error(void) { return smx::g_err; }
-extern "C" int smx_version(void) { return 1; }
+extern "C" int smx_version(void) { return SMX_VERSION; }
 extern "C" int smx_device_count(void)
 {
     int n = 0;
