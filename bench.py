@@ -473,27 +473,31 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
     if "saw_frames" in legs:
         # longer blocks of the same bank; 64 frames = the JACK operating point (linux/jack_midi.c:19-20)
         for frames in (8, 16, 32, 64, 1024):
-            carry = frames > 32 and voices * frames >= 1 << 30
-            # blocks of more than 32 frames have two exact forms: AUTO (default) lets the device pick from the bank's
+            # (blocks of 17..32 frames of >= 2^25-voice banks run as one 32-frame chunk of the same two forms;
+            # with STEPPING pinned they keep the direct form: saw_bank.hip, launch_saw_bank)
+            short = 16 < frames <= 32 and voices >= 1 << 25
+            carry = (frames > 32 and voices * frames >= 1 << 30) or short
+            # such blocks have two exact forms: AUTO (default) lets the device pick from the bank's
             # increments, STEPPING is the data-independent one (also what AUTO falls back to: DESIGN 3.2b)
-            for form in ((SMX_FORM_AUTO, SMX_FORM_STEPPING) if (carry and frames > 32) else (SMX_FORM_AUTO,)):
+            for form in ((SMX_FORM_AUTO, SMX_FORM_STEPPING) if carry else (SMX_FORM_AUTO,)):
                 big.bank.set_block_form(form)
                 reps = 50 if frames < 1024 else 5
                 ms = time_saw(big, frames, reps, 5 if frames < 1024 else 1)
                 if verify:
                     big.verify(frames, "saw bank %d frames" % frames, pick=sorted({0, frames // 2, frames - 1}))
-                events = carry and frames > 32 and form == SMX_FORM_AUTO
+                events = carry and form == SMX_FORM_AUTO
+                direct = not carry or (short and form == SMX_FORM_STEPPING)
                 # issue time of the stepping forms' inner loops; not defined when the wraps are located instead
-                valu = None if events else ("saw_carry" if carry else "saw_direct")
+                valu = None if events else ("saw_direct" if direct else "saw_carry")
                 out.append(saw_entry(
                     "saw bank, %d voices, %d frames/step%s" % (voices, frames, ", form STEPPING pinned" if form == SMX_FORM_STEPPING else ""),
                     voices, frames, ms, valu,
                     {"formulation": ("carry, wrap events (AUTO: picked on the device from the bank's increments)" if events
-                                     else "carry, stepping") if carry else "direct"}))
+                                     else "carry, stepping") if not direct else "direct"}))
                 if events:
                     # divisions, compares, selects, multiplies: mostly the 4.3-4.7-cycle class, some 2.7-cycle adds
                     with_recorded_issue(out[-1], ("saw_bank_event_long_kernel", "1024u") if frames >= 1024
-                                        else ("saw_bank_carry_kernel", "64, true"), 4.0)
+                                        else ("saw_bank_carry_kernel", "32, true" if short else "64, true"), 4.0)
         big.bank.set_block_form(SMX_FORM_AUTO)
     if "saw_hi" in legs:
         # the same 64-frame blocks on a bank of high voices only (MIDI notes 100..127: 3..17 wraps per voice per

@@ -680,8 +680,10 @@ static int bank_run_async(smx_bank *b, int n, const smx::SawPublish *pub, bool *
     rv = bank_bus_advance(b, (uint32_t)n, &bi, &bnext);
     if (rv) return rv;
     int form = b->block_form;
-    if (n > 32) b->long_tag++;                                           // this block's number (echoed with its pick)
-    if (form == SMX_FORM_AUTO && n > 32 && b->h_form) {
+    // "long" blocks: the ones that may take the carry formulations (saw_bank.hip: more than 32 frames, and 17..32
+    // frames as one 32-frame chunk unless the stepping form is asked for)
+    if (n > 16) b->long_tag++;                                           // this block's number (echoed with its pick)
+    if (form == SMX_FORM_AUTO && n > 16 && b->h_form) {
         const volatile uint32_t *hf = b->h_form;                         // whatever has landed: no sync
         const uint32_t seq = hf[1], seen = hf[0];
         if (seq != b->form_seq) {                                        // a long block was finalized since the last look

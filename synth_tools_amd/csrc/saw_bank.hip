@@ -436,8 +436,9 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
                            SawPartial *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
                            const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
 {
-    static_assert(!EVENTS || TC == 64, "the event form is built for 64-frame chunks");
-    static_assert(TC == 64, "frames per chunk");
+    static_assert(TC == 64 || TC == 32, "frames per chunk (32: blocks of 17..32 frames, one chunk)");
+    static_assert(TC == 64 || !MULTI, "a 32-frame chunk is the whole block");
+    constexpr uint32_t LG = TC == 64 ? 6 : 5;      // log2(TC)
     __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
     __shared__ unsigned long long S[1];            // U0
@@ -503,8 +504,8 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
             bool heavy[4], light[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t lo = vu[k] + (vi[k] << 6);
-                const uint32_t K = (vi[k] >> 26) + (lo < vu[k] ? 1u : 0u);
+                const uint32_t lo = vu[k] + (vi[k] << LG);
+                const uint32_t K = (vi[k] >> (32 - LG)) + (lo < vu[k] ? 1u : 0u);
                 heavy[k] = K >= 3u;
                 light[k] = K - 1u < 2u;
             }
@@ -532,19 +533,19 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
                 const uint2 en = list[e < nw ? e : 0u];
                 const uint32_t d = en.y;                          // > 0: an off voice never wraps
                 const float rd = rcp_biased(d);
-                // the voice wraps within the chunk, so ~u < 64 d: the first quotient is below 64
+                // the voice wraps within the chunk, so ~u < TC d: the first quotient is below TC (64 or 32)
                 const uint32_t n1 = div_small(~en.x, d, rd);
-                // Q < 64 exactly when d >= 2^26; a smaller increment wraps at most once per chunk and any
+                // Q < TC exactly when d >= 2^(32-LG); a smaller increment wraps at most once per chunk and any
                 // gap beyond the chunk is as good as any other (2^30 keeps et + gap from wrapping)
-                const uint32_t eq = (d >> 26) ? div_small(0xFFFFFFFFu, d, rd) : (1u << 30);
+                const uint32_t eq = (d >> (32 - LG)) ? div_small(0xFFFFFFFFu, d, rd) : (1u << 30);
                 const uint32_t erm = 0xFFFFFFFFu - eq * d;        // (meaningless, and unused, in the second case)
                 const uint32_t ee = d - 1u - erm;
                 uint32_t er = en.x + (n1 + 1u) * d;               // mod 2^32: the phase right after the first wrap
                 uint32_t et = e < nw ? n1 : 0xFFFFFFFFu;
-                // every gap is at least one frame, so 64 rounds always suffice: the bound makes the
+                // every gap is at least one frame, so TC rounds always suffice: the bound makes the
                 // loop finite whatever the data
-                for (int round = 0; round < 64 && __any(et < 64u); round++) {
-                    if (et < 64u) {
+                for (int round = 0; round < TC && __any(et < (uint32_t)TC); round++) {
+                    if (et < (uint32_t)TC) {
                         atomicAdd(&M[et][lane], 1u);             // own column: no lane ever shares an address
                         const bool c = er <= erm;
                         et += eq + (c ? 1u : 0u);
@@ -1233,7 +1234,19 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     const bool big = (unsigned long long)n_pad * nframes >= (1ull << carry_min_log2) ||
                      (!cm && n_pad >= (1u << 23) && nframes >= 64);
     // (banks from 2^16 voices: 256 Ki voices x 4096 frames 70 -> 44 us, x 16384 frames 260 -> 120 us)
-    if (nframes > 32 && n_pad >= (1u << 16) && big && d_scratch && !no_carry) {
+    // Blocks of 17..32 frames (round 3): under AUTO / EVENTS they take the same path as ONE 32-frame chunk -- the
+    // event form's work goes with the number of wraps, and a piano-range bank wraps 0.56 times per voice in 32
+    // frames (64 Mi voices x 32 frames: direct form 136 us = 49 % of HBM; see DESIGN 3.2b for the event form's
+    // figure).  A caller that pins the stepping form keeps the direct form there (equal within 3 %, and its
+    // fold is deferred).  SMX_SAW_NO_SHORT_EVENTS=1: as before (direct form up to 32 frames).
+    static const bool no_short = getenv("SMX_SAW_NO_SHORT_EVENTS") != nullptr;          // A/B switch
+    const bool short_chunk = nframes <= 32;
+    const bool carry_frames = nframes > 32 || (nframes > 16 && !no_short && long_block_form != SMX_FORM_STEPPING);
+    // (measured, piano-range banks, 17 / 24 / 32 frames alike -- the event form's cost is per voice, not per frame:
+    // 2^26 voices 138 -> 109 us, 2^25 77 -> 65, 2^24 44.4 -> 42.0, 2^23 26.3 -> 30.5: from 2^25 voices.  A bank above
+    // the rule's bound steps its 32 frames in 139.6 us against 138.5 for the direct form: profiles/r03_short_events.txt)
+    const bool big_short = cm ? big : n_pad >= (1u << 25);
+    if (carry_frames && n_pad >= (1u << 16) && (short_chunk ? big_short : big) && d_scratch && !no_carry) {
         // carry-count formulation: 1.5 vector ops per voice-sample
         const uint32_t ngroups = n_pad / 4;
         const uint32_t gy = (nframes + 63) / 64;
@@ -1300,6 +1313,11 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                     else            { if (nt) SMX_LONG_LAUNCH(true, 256);  else SMX_LONG_LAUNCH(false, 256); }
 #undef SMX_LONG_LAUNCH
                 }
+            } else if (short_chunk) {
+                // one 32-frame chunk (17..32 frames): as below
+                const uint32_t *f = force_events ? nullptr : flag;
+                if (!force_events) { if (nt) SMX_CARRY_LAUNCH(true, false, 32, false, f); else SMX_CARRY_LAUNCH(false, false, 32, false, f); }
+                if (nt) SMX_CARRY_LAUNCH(true, false, 32, true, f); else SMX_CARRY_LAUNCH(false, false, 32, true, f);
             } else {
                 // 64-frame chunks: both forms are queued, the device-side flag picks one (the other
                 // returns at once); the finalize kernel refreshes the flag from this launch's statistics

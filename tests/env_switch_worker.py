@@ -35,6 +35,29 @@ def main():
                 checks += 1
         assert np.array_equal(bank.read()[1], st), (n, "phases")
         bank.close()
+    # blocks of 17..32 frames of a 2^25-voice bank: one 32-frame chunk of the carry forms (SMX_SAW_NO_SHORT_EVENTS: the
+    # direct form); three frames per block against the closed form of the linear phasor
+    # (only in the processes whose switch touches that path, and in the one without a switch: the bank takes seconds to make)
+    other = ("SMX_POLY_NO_DEFER", "SMX_PDM_NO_FEWTICKS", "SMX_NO_PUBLISH", "SMX_BANK_TWO_ALLOCS", "SMX_SAW_NO_LONG_EVENTS",
+             "SMX_SAW_NO_SLOTS", "SMX_SAW_NO_DEFER")
+    n = 1 << 25
+    inc, st = synthetic.saw_bank(n, 0x5EED0E05, tab, active_fraction=0.9) if not any(os.environ.get(k) for k in other) else (None, None)
+    bank = sta.SawBank(n if inc is not None else 64)
+    if inc is not None:
+        bank.load(inc, st)
+    for k, nf in enumerate((32, 20, 32, 32) if inc is not None else ()):
+        bank.run_async(nf)
+        if k != 1:
+            pick = [0, nf // 2, nf - 1]
+            with np.errstate(over="ignore"):
+                want = [int(np.where(inc != 0, (st + np.uint32(f) * inc).view(np.int32) >> 4, 0).sum(dtype=np.int64)) for f in pick]
+            want = ((np.array(want, np.int64) + (1 << 31)) % (1 << 32) - (1 << 31)).astype(np.int32)
+            assert np.array_equal(bank.fetch(nf)[0][pick], want), ("short chunk", k, nf)
+            checks += 1
+        with np.errstate(over="ignore"):
+            st += np.uint32(nf) * inc
+    assert inc is None or np.array_equal(bank.read()[1], st), "short chunk phases"
+    bank.close()
     # the drop-in synth_run on a caller-owned struct synth (one launch that publishes its own bus; SMX_NO_PUBLISH:
     # upload + bank kernel + copy), against the REFERENCE's committed outputs: 1-, 64-, 256- and 4096-frame blocks
     import replay

@@ -726,3 +726,41 @@ def test_load_run_replaces_both_arrays_on_any_bank(smx, orc, inc_table, n):
     ginc, gst = bank.read()
     assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
     bank.close()
+
+
+@pytest.mark.parametrize("form", [0, 2, 1])
+def test_short_chunk_forms_17_to_32_frames(smx, orc, inc_table, form):
+    """Blocks of 17..32 frames of a >= 2^25-voice bank run as ONE 32-frame chunk of the carry formulations (AUTO: the
+    device-side flag picks stepping or located wraps; EVENTS pinned; STEPPING pinned keeps the direct form): a ragged
+    bank with off voices, every frame count of the class next to its neighbours (16, 33, 64) and the tick kernel,
+    un-fetched blocks in between, a note far above the event form's bound (AUTO must step from the next block on), a
+    reload; three frames of every fetched bus against the closed form of the linear phasor, and the final phases."""
+    n = (1 << 25) + 4096 + 7
+    rng = np.random.default_rng(0x5C17 + form)
+    inc, state = synthetic.saw_bank(n, 0x5EED0C17, inc_table, active_fraction=0.9)
+    bank = smx.SawBank(n)
+    bank.load(inc, state)
+    bank.set_block_form(form)
+    st, inc = state.copy(), inc.copy()
+    n2v = np.zeros(128, np.int32)
+    frames = [32, 32, 32, 32, 32, 32, 17, 24, 31, 18, 16, 33, 64, 32, 1, 25, 32, 32]
+    for step, nf in enumerate(frames + [int(x) for x in rng.integers(15, 35, 10)]):
+        if step == 12:
+            if form == 0:
+                assert bank.next_block_form() == 2                 # a piano-range bank: inside the rule
+            bank.note_on(127)                                      # 13.3 wraps per 64 frames: above the bound
+            orc.orc_note_on(n2v, inc, n, 127)
+            if form == 0:
+                assert bank.next_block_form() == 1
+        if step == 20:
+            inc = synthetic.saw_bank(n, 0x5EED0C18, inc_table, active_fraction=0.8)[0]
+            bank.load(inc=inc)
+        bank.run_async(nf)
+        if step % 3 != 1:
+            pick = sorted({0, nf // 2, nf - 1})
+            assert np.array_equal(bank.fetch(nf)[0][pick], _bus_at(inc, st, pick)), (form, step, nf)
+        with np.errstate(over="ignore"):
+            st += np.uint32(nf) * inc
+    ginc, gst = bank.read()
+    assert np.array_equal(ginc, inc) and np.array_equal(gst, st)
+    bank.close()
