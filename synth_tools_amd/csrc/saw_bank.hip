@@ -893,6 +893,9 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
     __shared__ uint32_t Ws[4][64], Mx[4];
     const uint32_t tid = threadIdx.x, t = tid & 63, part = tid >> 6;
     SawPartial *p = partial + (size_t)blockIdx.x * SAW_SLOTS;
+    // (requested together with the slots: this kernel is a chain of memory round trips, ~2 us each, on the tail of
+    // every long block -- the layout word above is not even read when the launch cannot have filled a long layout)
+    const unsigned long long I = saw_stats_sum_inc(mode_flag);
     // all loads first (16 independent ones per thread in flight), then the clearing stores
     unsigned long long lv[SAW_SLOTS / 4], uv[SAW_SLOTS / 4];
     uint32_t wv[SAW_SLOTS / 4];
@@ -923,7 +926,6 @@ void saw_bank_finalize_kernel(SawPartial *__restrict__ partial,
     if (part == 0) {
         const unsigned long long L = Ls[0][t] + Ls[1][t] + Ls[2][t] + Ls[3][t];
         const unsigned long long U0 = Us[0][0] + Us[1][0] + Us[2][0] + Us[3][0];
-        const unsigned long long I = saw_stats_sum_inc(mode_flag);
         // W(t): carries of the frames before t (only mod 16 matters) -- exclusive prefix sum over
         // the 64 lanes of this wave (part == 0 is exactly wave 0; lane == t)
         const uint32_t mine = Ws[0][t] + Ws[1][t] + Ws[2][t] + Ws[3][t];
@@ -1341,7 +1343,8 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                 if (published) *published = true;
             }
             hipLaunchKernelGGL(saw_bank_finalize_kernel, dim3(gy), dim3(256), 0, stream, part, d_bus,
-                               d_bus_next, nframes, n_pad, flag, ran_long, host_flag, host_tag, fin_pub);
+                               d_bus_next, nframes, n_pad, flag, long_layout_possible ? ran_long : nullptr, host_flag,
+                               host_tag, fin_pub);
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         }
