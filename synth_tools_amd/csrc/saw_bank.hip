@@ -1257,6 +1257,10 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
         // 2048 (all resident at once) as long as that keeps the trip count within the counters' range
         uint32_t total = cg ? (uint32_t)atoi(cg) : 4096u;
         if (!cg && gy == 1 && (ngroups + 2048u * 256u - 1) / (2048u * 256u) <= 400) total = 2048u;
+        // banks of up to 2^24 voices: half as many again (8 Mi voices x 64 frames 43.6 -> 40.9 us, 16 Mi 69.5 -> 66.6;
+        // from 32 Mi voices up 1024 .. 2560 workgroups are within 1 %: profiles/r03_carry_grid.txt)
+        const bool mid_bank = !cg && gy == 1 && n_pad <= (1u << 24);
+        if (mid_bank) total = 1024u;
         uint32_t gx = (total + gy - 1) / gy;
         if (gx > (ngroups + 255) / 256) gx = (ngroups + 255) / 256;
         // the packed 16-bit scalar counters take 128 carries per trip: stay below 400 trips
@@ -1273,7 +1277,8 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             const bool force_events = long_block_form == SMX_FORM_EVENTS;
             // the event form's rows take unequal time: more, shorter workgroups balance better
             // (64 Mi voices: 64 frames 198 us with 2048, 189 with 4096; 1024 frames 2.68 / 2.56 ms with 4096 / 8192)
-            uint32_t gx_ev = ((cg ? (uint32_t)atoi(cg) : (gy == 1 ? 4096u : 8192u)) + gy - 1) / gy;
+            // (banks of up to 2^24 voices, one chunk: 2048 -- 8 Mi voices x 64 frames 33.4 -> 30.5 us, 16 Mi 48.3 -> 46.5)
+            uint32_t gx_ev = ((cg ? (uint32_t)atoi(cg) : (mid_bank ? 2048u : gy == 1 ? 4096u : 8192u)) + gy - 1) / gy;
             if (gx_ev > (ngroups + 255) / 256) gx_ev = (ngroups + 255) / 256;
             uint32_t *ran_long = flag + 1;                    // which slot layout the launch filled
             static const bool wide = getenv("SMX_SAW_NO_WIDE") == nullptr;          // A/B switch: carry masks instead of 64-bit pairs
