@@ -172,7 +172,7 @@ void pdm_bank_kernel(const uint32_t *__restrict__ setpoint,
 // channels) is in its way.  Here: one lane per channel, four 64-channel words per wave and trip (eight 4-byte loads in
 // flight per lane), the wave's carry-outs of a tick are the compare mask of the add (__ballot: the rrx register, 64
 // wide), and lane 0 stores it as one 64-bit word of the tick-major matrix.
-template <bool DITHER>
+template <bool DITHER, bool ONE>
 __global__ __launch_bounds__(256)
 void pdm_fewticks_kernel(const uint32_t *__restrict__ setpoint, const uint32_t *__restrict__ accu,
                          const uint32_t *__restrict__ dither, unsigned long long *__restrict__ bits64,
@@ -199,20 +199,45 @@ void pdm_fewticks_kernel(const uint32_t *__restrict__ setpoint, const uint32_t *
             sp[k] = __builtin_nontemporal_load(setpoint + ch);
             a[k] = __builtin_nontemporal_load(accu + ch);
         }
+        if constexpr (ONE) {
+            // one tick: lane 0 stores each word as soon as its two loads are there (measured against the form below
+            // on one box: 86.3 vs 89-91.6 us for 64 Mi channels -- the stream should not wait for all eight loads)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t base = (w0 + k) * 64u;
-            // padding channels (setpoint 0) would still pulse under dither: masked beyond the last real channel
-            const unsigned long long vmask = base + 64u <= n ? ~0ull : (base < n ? (1ull << (n - base)) - 1ull : 0ull);
-            uint32_t acc = a[k] + elapsed * sp[k] + dsum0;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t base = (w0 + k) * 64u;
+                const unsigned long long vm = base + 64u <= n ? ~0ull : (base < n ? (1ull << (n - base)) - 1ull : 0ull);
+                const uint32_t x = sp[k] + d[0];
+                const uint32_t acc1 = a[k] + elapsed * sp[k] + dsum0 + x;
+                const unsigned long long m1 = __ballot(acc1 < x);          // carry out of accu += x
+                if (lane == 0) bits64[w0 + k] = m1 & vm;
+            }
+            continue;
+        }
+        // The four words of a tick leave the wave as ONE store instruction: lanes 0..3 take the four carry masks (the
+        // rrx registers of words w0..w0+3) and write 32 contiguous bytes -- one memory transaction per tick and trip
+        // instead of four 8-byte ones from lane 0 (round 3: the store transactions, not the arithmetic, were what a
+        // second tick cost: 64 Mi channels x 2 ticks 112.8 us against 85.0 for one tick).
+        // padding channels (setpoint 0) would still pulse under dither: masked beyond the last real channel
+        const uint32_t mybase = (w0 + (lane & 3u)) * 64u;
+        const unsigned long long vmask = mybase + 64u <= n ? ~0ull : (mybase < n ? (1ull << (n - mybase)) - 1ull : 0ull);
+        uint32_t acc[4];
 #pragma unroll
-            for (int t = 0; t < 8; t++) {                                  // (static indices: d[] stays in registers)
-                if ((uint32_t)t < nticks) {                                // wave-uniform
+        for (int k = 0; k < 4; k++) acc[k] = a[k] + elapsed * sp[k] + dsum0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {                                      // (static indices: d[] stays in registers)
+            if ((uint32_t)t < nticks) {                                    // wave-uniform
+                unsigned long long m[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
                     const uint32_t x = sp[k] + d[t];
-                    acc += x;
-                    const unsigned long long m = __ballot(acc < x);       // carry out of accu += x
-                    if (lane == 0) bits64[(size_t)t * words64_per_tick + w0 + k] = m & vmask;
+                    acc[k] += x;
+                    m[k] = __ballot(acc[k] < x);                           // carry out of accu += x
                 }
+                unsigned long long v = m[0];
+                v = lane == 1 ? m[1] : v;
+                v = lane == 2 ? m[2] : v;
+                v = lane == 3 ? m[3] : v;
+                if (lane < 4) bits64[(size_t)t * words64_per_tick + w0 + lane] = v & vmask;
             }
         }
     }
@@ -339,21 +364,23 @@ int launch_pdm_bank(const uint32_t *d_setpoint, const uint32_t *d_accu,
     if (nticks == 0) return SMX_OK;
     static const bool no_few = getenv("SMX_PDM_NO_FEWTICKS") != nullptr;          // A/B switch
     static const char *fmax = getenv("SMX_PDM_FEWTICKS_MAX");                     // tuning override (1..8)
-    // (64 Mi channels: 1 tick 86.7 us against 121 us for the tile kernel, 2 ticks 117.8 against 128.6; 4 ticks 173 against
-    // 137, 8 ticks 272 against 142: a 64-bit store per wave and tick does not scale -- profiles/r03_pdm_few_sweep.txt)
-    const uint32_t few_max = fmax ? (uint32_t)atoi(fmax) : 2u;
+    // (64 Mi channels, profiles/r03_pdm_few_sweep.txt: 1 tick 86 us against 120 for the tile kernel; with one 32-byte
+    // store per tick and wave-trip 2 ticks 96 against 122, 3 ticks 104 against 122, 4 ticks 110 against 123, 6 ticks
+    // 123-125 against 125, 8 ticks 137 against 129 -- with a 64-bit store per word from lane 0 it was 114 / 140 / 164 /
+    // 212 / 265: the store transactions were what a further tick cost)
+    const uint32_t few_max = fmax ? (uint32_t)atoi(fmax) : 4u;
     if (nticks <= few_max && nticks <= 8 && n_pad >= (1u << 20) && !no_few) {
         // the tick ABI on a big bank: a read stream (pdm_fewticks_kernel)
         auto *b64f = reinterpret_cast<unsigned long long *>(d_bits);
         const uint32_t w64 = n_pad / 64;
         uint32_t gx = w64 / 16;                              // one trip of 4 waves x 4 words per workgroup at least
         if (gx > 2048) gx = 2048;
-        if (d_dither)
-            hipLaunchKernelGGL(pdm_fewticks_kernel<true>, dim3(gx), dim3(256), 0, stream, d_setpoint, d_accu, d_dither,
-                               b64f, w64, nticks, n, elapsed, d_dsum_in, d_dsum_out);
-        else
-            hipLaunchKernelGGL(pdm_fewticks_kernel<false>, dim3(gx), dim3(256), 0, stream, d_setpoint, d_accu, d_dither,
-                               b64f, w64, nticks, n, elapsed, d_dsum_in, d_dsum_out);
+#define SMX_FEW(D_, ONE_)                                                                                       \
+    hipLaunchKernelGGL((pdm_fewticks_kernel<D_, ONE_>), dim3(gx), dim3(256), 0, stream, d_setpoint, d_accu,     \
+                       d_dither, b64f, w64, nticks, n, elapsed, d_dsum_in, d_dsum_out)
+        if (d_dither) { if (nticks == 1) SMX_FEW(true, true); else SMX_FEW(true, false); }
+        else          { if (nticks == 1) SMX_FEW(false, true); else SMX_FEW(false, false); }
+#undef SMX_FEW
         SMX_HIP(hipGetLastError());
         return SMX_OK;
     }
