@@ -631,13 +631,18 @@ struct SawPartialL {
     uint32_t H[256];              // voices per (phase & 15, inc & 15) class
     uint32_t W[TL];               // wraps at frame t (t -> t+1)
 };
-constexpr uint32_t SAW_LONG = 256;         // shortest launch that takes the long event form
+// Shortest launch that takes the long event form.  Round 3: every launch of more than 64 frames -- the kernel locates
+// wraps only up to the frames the block needs (tlim), so 65..255 frames are ONE pass over the bank instead of two to
+// four 64-frame chunks (64 Mi voices, piano range: 65 frames 243 -> 178 us, 128 frames 244 -> 210, 192 frames 360 ->
+// 242, 255 frames 465 -> 273; 16 Mi voices x 128 frames 80.9 -> 68.7: profiles/r03_long_min.txt).  Rounds 1-2: 256.
+constexpr uint32_t SAW_LONG_DEFAULT = 65;
 
 template <bool NT, uint32_t TL>
 __global__ __launch_bounds__(256)
 void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
                                 SawPartialL<TL> *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
-                                const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
+                                const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long,
+                                uint32_t nframes)
 {
     static_assert(TL == 256 || TL == 1024, "chunk lengths of the long event form");
     constexpr uint32_t LG = TL == 256 ? 8 : 10;
@@ -651,6 +656,10 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ran_long = TL == 256 ? 1u : 2u;   // slot layout of this launch
     const uint32_t t0 = tbase + blockIdx.y * TL;
+    // frames of this chunk that the block needs (the last chunk of a launch, or a launch shorter than the chunk:
+    // 128..255 frames run as one 256-frame chunk -- the bank is read once instead of two to four times): wraps
+    // beyond them are not located
+    const uint32_t tlim = min(TL, nframes - blockIdx.y * TL);
     for (uint32_t i = tid; i < TL; i += 256) hist[i] = 0;
     H[tid] = 0;
     if (tid < 2) S[tid] = 0;
@@ -734,8 +743,8 @@ void saw_bank_event_long_kernel(const uint32_t *__restrict__ inc, const uint32_t
             uint32_t er = en.x + (n1 + 1u) * d;               // the phase right after the first wrap
             uint32_t et = e < nw ? n1 : 0xFFFFFFFFu;
             // every gap is at least one frame: TL rounds always suffice
-            for (uint32_t round = 0; round < TL && __any(et < TL); round++) {
-                if (et < TL) {
+            for (uint32_t round = 0; round < TL && __any(et < tlim); round++) {
+                if (et < tlim) {
                     atomicAdd(&hist[et], 1u);
                     const bool cc = er <= erm;
                     et += eq + (cc ? 1u : 0u);
@@ -1300,7 +1309,9 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
     } while (0)
             const bool nt = n_pad >= (1u << 24);
             static const bool no_long = getenv("SMX_SAW_NO_LONG_EVENTS") != nullptr;          // A/B switch
-            if (nframes >= SAW_LONG && !no_long) {
+            static const char *lm = getenv("SMX_SAW_LONG_MIN");                               // tuning override (frames)
+            static const uint32_t saw_long = lm ? (uint32_t)atoi(lm) : SAW_LONG_DEFAULT;
+            if (nframes >= saw_long && !no_long) {
                 // long launches: the stepping form in 64-frame chunks and the event form in 256-frame
                 // chunks (divisions paid once per 256 frames) are queued, the flag picks one; the
                 // finalize kernel reads from `ran_long` which slot layout was filled
@@ -1315,7 +1326,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                     if (gxl > (ngroups + 255) / 256) gxl = (ngroups + 255) / 256;
 #define SMX_LONG_LAUNCH(NT_, TL_)                                                                            \
     hipLaunchKernelGGL((saw_bank_event_long_kernel<NT_, TL_>), dim3(gxl, gyl), dim3(256), 0, stream, d_inc, \
-                       d_state_in, reinterpret_cast<SawPartialL<TL_> *>(part), ngroups, tbase, f, ran_long)
+                       d_state_in, reinterpret_cast<SawPartialL<TL_> *>(part), ngroups, tbase, f, ran_long, nframes)
                     if (tl == 1024) { if (nt) SMX_LONG_LAUNCH(true, 1024); else SMX_LONG_LAUNCH(false, 1024); }
                     else            { if (nt) SMX_LONG_LAUNCH(true, 256);  else SMX_LONG_LAUNCH(false, 256); }
 #undef SMX_LONG_LAUNCH
@@ -1342,7 +1353,7 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
 #undef SMX_CARRY_LAUNCH_W
             // a single 64-frame chunk ends in ONE workgroup of the finalize kernel: it may hand the bus to the host
             SawPublish fin_pub{};
-            const bool long_layout_possible = nframes >= SAW_LONG && !no_long;
+            const bool long_layout_possible = nframes >= saw_long && !no_long;
             if (pub && pub->hflag && gy == 1 && !long_layout_possible) {
                 fin_pub = *pub;
                 if (published) *published = true;

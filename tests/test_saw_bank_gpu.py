@@ -225,9 +225,10 @@ def test_long_block_forms_agree(smx, orc, inc_table, form):
     on arbitrary 32-bit increments (many wraps per voice: the event loop runs long, the result must
     not care), on all-wrap / never-wrap / half-scale increments, with voices off, over single
     chunks, partial chunks and multi-chunk launches, and across a reload of the increments.
-    A 2^24-voice bank for blocks up to 200 frames (64-frame chunks), a 2^22-voice bank for 256
+    A 2^24-voice bank for blocks up to 255 frames (64-frame chunks when stepping; the event form runs 65..255 frames
+    as ONE 256-frame chunk that locates wraps only up to the block's last frame), a 2^22-voice bank for 256
     frames and more (256-frame chunks in the event form, 1024-frame chunks from 1024 frames)."""
-    for n, piano_blocks, hard_blocks in (((1 << 24) + 2048, [64, 64, 130, 33, 1, 200], [64, 100]),
+    for n, piano_blocks, hard_blocks in (((1 << 24) + 2048, [64, 64, 130, 33, 1, 200], [64, 100, 65, 255]),
                                          ((1 << 22) + 1024, [256, 300, 64, 513, 1024, 1030], [256, 257, 1025])):
         inc, state = synthetic.saw_bank(n, 0x5EED0E0E, inc_table, active_fraction=0.9)
         bank = smx.SawBank(n)

@@ -2,7 +2,8 @@
 32 frames took before), AUTO (one 32-frame chunk: the device-side flag picks stepping or located wraps) and the event
 form pinned -- checked against the closed form of the linear phasor, then timed in a stream of un-fetched blocks.
     python tools/explore_short_events.py            -> us per block, per bank / frame count / form
-    SMX_SAW_CARRY_MIN_LOG2=28 python tools/...      -> the same with smaller banks admitted to the chunk path"""
+    SMX_SAW_CARRY_MIN_LOG2=28 python tools/...      -> the same with smaller banks admitted to the chunk path
+    LGS=26 FRAMES=128,192,256 python tools/...       -> other banks (log2 of the voice count) / block lengths"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -31,10 +32,10 @@ def main():
                 inc = (inc | np.uint32(0xC0000000)).astype(np.uint32)         # every voice above the event form's bound
             b = sta.SawBank(n)
             b.load(inc, st)
-            for nf in (17, 24, 32, 64):
+            for nf in [int(x) for x in os.environ.get("FRAMES", "17,24,32,64").split(",")]:
                 row = {}
                 for form, name in ((1, "direct"), (0, "auto"), (2, "events")):
-                    if kind == "high" and form == 2 and nf == 64:
+                    if kind == "high" and form == 2 and nf >= 64:
                         continue
                     b.set_block_form(form)
                     b.load(state=st)
