@@ -434,21 +434,24 @@ template <bool NT, bool MULTI, int TC, bool EVENTS, bool WIDE = false, int NTH =
 __global__ __launch_bounds__(NTH)
 void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__restrict__ st_in,
                            SawPartial *__restrict__ partial, uint32_t ngroups, uint32_t tbase,
-                           const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long)
+                           const uint32_t *__restrict__ mode_flag, uint32_t *__restrict__ ran_long,
+                           uint32_t nframes)            // EVENTS: the block's frames (wraps beyond them are not located)
 {
-    static_assert(TC == 64 || TC == 32, "frames per chunk (32: blocks of 17..32 frames, one chunk)");
-    static_assert(TC == 64 || !MULTI, "a 32-frame chunk is the whole block");
-    constexpr uint32_t LG = TC == 64 ? 6 : 5;      // log2(TC)
-    __shared__ uint32_t M[64][65];                 // [frame][lane] carry counts; column 64: scalar counts
+    static_assert(TC == 64 || TC == 32 || (TC == 128 && EVENTS),
+                  "frames per chunk (32: blocks of 17..32 frames, one chunk; 128: blocks of 65..128 frames, event form)");
+    static_assert(TC == 64 || !MULTI, "a 32- or 128-frame chunk is the whole block");
+    constexpr uint32_t LG = TC == 128 ? 7 : TC == 64 ? 6 : 5;      // log2(TC)
+    constexpr int TCM = TC > 64 ? TC : 64;         // frames of the counting matrix (whole 64-frame slot rows)
+    __shared__ uint32_t M[TCM][65];                // [frame][lane] carry counts; column 64: scalar counts
     __shared__ uint32_t H[256];                    // histogram of (phase & 15, inc & 15)
-    __shared__ unsigned long long S[1];            // U0
+    __shared__ unsigned long long S[2];            // U0 of the chunk's first (and, TC == 128, second) 64-frame row
     __shared__ uint32_t MX;                        // largest increment
     __shared__ uint2 EL[EVENTS ? (NTH / 64) * 256 : 1];     // EVENTS: per wave, the (phase, inc) of the voices that wrap
     if (mode_flag && (*mode_flag != 0u) != EVENTS) return;     // the other form runs this launch
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     if (ran_long && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ran_long = 0;   // 64-frame slot layout
     const uint32_t t0 = tbase + (MULTI ? blockIdx.y * 64u : 0u);   // phase offset of this chunk
-    for (uint32_t i = tid; i < 64 * 65; i += NTH) (&M[0][0])[i] = 0;
+    for (uint32_t i = tid; i < (uint32_t)TCM * 65u; i += NTH) (&M[0][0])[i] = 0;
     if (tid < 256) H[tid] = 0;
     if (tid < 2) S[tid] = 0;
     if (tid == 0) MX = 0;
@@ -462,7 +465,7 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
 #pragma unroll
         for (int t = 0; t < 32; t++) W[t] = 0;
     }
-    unsigned long long sumU = 0;
+    unsigned long long sumU = 0, sumU2 = 0;        // sumU2 (TC == 128): the phases at the second row's first frame
     uint32_t mx = 0;
 
     // ngroups is a multiple of 256 (n_pad of 1024): whole workgroup rows, so the trip count is
@@ -489,6 +492,8 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
         uint32_t u2 = (a.z ? b.z + t0 * a.z : 0u) ^ 0x80000000u;
         uint32_t u3 = (a.w ? b.w + t0 * a.w : 0u) ^ 0x80000000u;
         sumU += (unsigned long long)u0 + u1 + u2 + u3;
+        if constexpr (TC == 128)      // offset-binary phases 64 frames on (mod 2^32 each): the second slot row's U0
+            sumU2 += (unsigned long long)(u0 + (a.x << 6)) + (u1 + (a.y << 6)) + (u2 + (a.z << 6)) + (u3 + (a.w << 6));
         atomicAdd(&H[((u0 & 15) << 4) | (a.x & 15)], 1u);
         atomicAdd(&H[((u1 & 15) << 4) | (a.y & 15)], 1u);
         atomicAdd(&H[((u2 & 15) << 4) | (a.z & 15)], 1u);
@@ -544,8 +549,11 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
                 uint32_t et = e < nw ? n1 : 0xFFFFFFFFu;
                 // every gap is at least one frame, so TC rounds always suffice: the bound makes the
                 // loop finite whatever the data
-                for (int round = 0; round < TC && __any(et < (uint32_t)TC); round++) {
-                    if (et < (uint32_t)TC) {
+                // the chunk's frames that the block needs: a 65-frame block in a 128-frame chunk, a 40-frame block in a
+                // 64-frame one, the last chunk of a MULTI launch
+                const uint32_t tlim = min((uint32_t)TC, nframes - (MULTI ? blockIdx.y * 64u : 0u));
+                for (int round = 0; round < TC && __any(et < tlim); round++) {
+                    if (et < tlim) {
                         atomicAdd(&M[et][lane], 1u);             // own column: no lane ever shares an address
                         const bool c = er <= erm;
                         et += eq + (c ? 1u : 0u);
@@ -589,34 +597,44 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     if (lane == 0) atomicMax(&MX, mx);
     for (int o = 32; o > 0; o >>= 1) sumU += __shfl_xor(sumU, o);
     if (lane == 0) atomicAdd(&S[0], sumU);
+    if constexpr (TC == 128) {
+        for (int o = 32; o > 0; o >>= 1) sumU2 += __shfl_xor(sumU2, o);
+        if (lane == 0) atomicAdd(&S[1], sumU2);
+    }
     __syncthreads();
 
-    SawPartial *out = partial + (size_t)blockIdx.y * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
-    if (tid < 256) {   // carries per frame: 4 lanes x 16 columns (+ column 64)
-        const uint32_t t = tid >> 2, q = tid & 3;
-        uint32_t s = (q == 0) ? M[t][64] : 0u;
+    // a 128-frame chunk fills two 64-frame slot rows, as two chunks of a MULTI launch would: the second row's frames
+    // count from its own first frame (the finalize kernel's W(t) and t * I are relative to the row's U0)
 #pragma unroll
-        for (int j = 0; j < 16; j++) s += M[t][q * 16 + j];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (q == 0) atomicAdd(&out->W[t], s);
-    }
-    if (tid < 256) {   // low-nibble sums per frame from the histogram: 4 lanes x 64 bins per frame.  A workgroup
-        // sees at most 400 rows x 1024 voices < 2^19 voices (launch_saw_bank), a bin count fits 24
-        // bits and 64 bins x count x 15 < 2^31: 32-bit v_mad_u32_u24 sums, widened at the end.
-        const uint32_t t = tid >> 2, q = tid & 3;
-        uint32_t l32 = 0;
-#pragma unroll 8
-        for (uint32_t k = 0; k < 64; k++) {
-            const uint32_t bin = q * 64 + k;
-            l32 = __umul24(H[bin], ((bin >> 4) + t * (bin & 15)) & 15) + l32;
+    for (int half = 0; half < TCM / 64; half++) {
+        SawPartial *out = partial + (size_t)(blockIdx.y + half) * SAW_SLOTS + (blockIdx.x % SAW_SLOTS);
+        if (tid < 256) {   // carries per frame: 4 lanes x 16 columns (+ column 64)
+            const uint32_t t = tid >> 2, q = tid & 3;
+            uint32_t s = (q == 0) ? M[64 * half + t][64] : 0u;
+#pragma unroll
+            for (int j = 0; j < 16; j++) s += M[64 * half + t][q * 16 + j];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if (q == 0) atomicAdd(&out->W[t], s);
         }
-        unsigned long long l = l32;
-        l += __shfl_xor(l, 1);
-        l += __shfl_xor(l, 2);
-        if (q == 0) atomicAdd(&out->L[t], l);
+        if (tid < 256) {   // low-nibble sums per frame from the histogram: 4 lanes x 64 bins per frame.  A workgroup
+            // sees at most 400 rows x 1024 voices < 2^19 voices (launch_saw_bank; 2^20 with 1024 threads: 64 bins x
+            // count x 15 stays below 2^32), a bin count fits 24 bits: 32-bit v_mad_u32_u24 sums, widened at the end.
+            // (the second row's histogram is the first one's: 64 * (inc & 15) = 0 mod 16)
+            const uint32_t t = tid >> 2, q = tid & 3;
+            uint32_t l32 = 0;
+#pragma unroll 8
+            for (uint32_t k = 0; k < 64; k++) {
+                const uint32_t bin = q * 64 + k;
+                l32 = __umul24(H[bin], ((bin >> 4) + t * (bin & 15)) & 15) + l32;
+            }
+            unsigned long long l = l32;
+            l += __shfl_xor(l, 1);
+            l += __shfl_xor(l, 2);
+            if (q == 0) atomicAdd(&out->L[t], l);
+        }
+        if (tid == 0) { atomicAdd(&out->U0, S[half]); atomicMax(&out->maxinc, MX); }
     }
-    if (tid == 0) { atomicAdd(&out->U0, S[0]); atomicMax(&out->maxinc, MX); }
 }
 
 // The event form for launches of 256 frames and more: 256-frame chunks, so that the divisions are
@@ -1297,13 +1315,13 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
             const bool ev512 = !ev256_env && (ngroups % 512u) == 0;
 #define SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, W_, FLAG_)                                                  \
     hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, EV_, W_>), dim3((EV_) ? gx_ev : gx, gy),    \
-                       dim3(256), 0, stream, d_inc, d_state_in, part, ngroups, tbase, FLAG_, ran_long)
+                       dim3(256), 0, stream, d_inc, d_state_in, part, ngroups, tbase, FLAG_, ran_long, nframes)
 #define SMX_CARRY_LAUNCH(NT_, MULTI_, TC_, EV_, FLAG_)                                                        \
     do {                                                                                                      \
         if ((EV_) && ev512)                                                                              \
             hipLaunchKernelGGL((saw_bank_carry_kernel<NT_, MULTI_, TC_, true, false, 512>),                   \
                                dim3((gx_ev + 1) / 2, gy), dim3(512), 0, stream, d_inc, d_state_in, part,      \
-                               ngroups, tbase, FLAG_, ran_long);                                              \
+                               ngroups, tbase, FLAG_, ran_long, nframes);                                     \
         else if ((EV_) || !wide) SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, EV_, false, FLAG_);                     \
         else                SMX_CARRY_LAUNCH_W(NT_, MULTI_, TC_, false, true, FLAG_);                         \
     } while (0)
@@ -1321,7 +1339,22 @@ int launch_saw_bank(const uint32_t *d_inc, const uint32_t *d_state_in, int32_t *
                 if (!force_events) {
                     if (nt) SMX_CARRY_LAUNCH(true, true, 64, false, f); else SMX_CARRY_LAUNCH(false, true, 64, false, f);
                 }
-                if (!no_events) {
+                // 65..128 frames (round 3): the 64-frame event kernel with a 128-frame counting matrix in 1024-thread
+                // workgroups (two slot rows, filled as two chunks would: the stepping form's layout) -- its per-voice
+                // cost is the 64-frame kernel's, which the 256-frame kernel with its counting sort does not reach
+                // (SMX_SAW_NO_EVENTS_128=1: the 256-frame chunk)
+                static const bool no_ev128 = getenv("SMX_SAW_NO_EVENTS_128") != nullptr;          // A/B switch
+                if (!no_events && nframes <= 128 && !no_ev128 && (ngroups % 1024u) == 0) {
+                    uint32_t gx128 = (cg ? (uint32_t)atoi(cg) : (mid_bank ? 2048u : 4096u)) / 4u;     // 1024-thread workgroups
+                    if (gx128 > ngroups / 1024u) gx128 = ngroups / 1024u;
+                    if (gx128 < 1) gx128 = 1;
+                    if (nt)
+                        hipLaunchKernelGGL((saw_bank_carry_kernel<true, false, 128, true, false, 1024>), dim3(gx128), dim3(1024),
+                                           0, stream, d_inc, d_state_in, part, ngroups, tbase, f, ran_long, nframes);
+                    else
+                        hipLaunchKernelGGL((saw_bank_carry_kernel<false, false, 128, true, false, 1024>), dim3(gx128), dim3(1024),
+                                           0, stream, d_inc, d_state_in, part, ngroups, tbase, f, ran_long, nframes);
+                } else if (!no_events) {
                     uint32_t gxl = ((cg ? (uint32_t)atoi(cg) : 8192u) + gyl - 1) / gyl;
                     if (gxl > (ngroups + 255) / 256) gxl = (ngroups + 255) / 256;
 #define SMX_LONG_LAUNCH(NT_, TL_)                                                                            \

@@ -20,7 +20,7 @@ def main():
     # (voices, block lengths): direct slot launches, tick launches, carry forms (stepping and events), small banks
     for n, frames, form in (((1 << 20) + 3, (8, 16, 64, 64, 3, 100, 32), 0),
                             (1 << 23, (64, 128, 64), 1),               # carry, stepping pinned
-                            (1 << 23, (64, 300, 64), 2),               # carry, events pinned (incl. a long launch)
+                            (1 << 23, (64, 300, 64, 100, 128, 65), 2), # carry, events pinned (incl. a long launch and 65..128 frames)
                             (70000, (64, 1, 17, 200), 0)):
         inc, st = synthetic.saw_bank(n, 0x5EED0E00 + n % 977, tab, active_fraction=0.9)
         bank = sta.SawBank(n)
@@ -39,7 +39,7 @@ def main():
     # direct form); three frames per block against the closed form of the linear phasor
     # (only in the processes whose switch touches that path, and in the one without a switch: the bank takes seconds to make)
     other = ("SMX_POLY_NO_DEFER", "SMX_PDM_NO_FEWTICKS", "SMX_NO_PUBLISH", "SMX_BANK_TWO_ALLOCS", "SMX_SAW_NO_LONG_EVENTS",
-             "SMX_SAW_NO_SLOTS", "SMX_SAW_NO_DEFER")
+             "SMX_SAW_NO_SLOTS", "SMX_SAW_NO_DEFER", "SMX_SAW_NO_EVENTS_128")
     n = 1 << 25
     inc, st = synthetic.saw_bank(n, 0x5EED0E05, tab, active_fraction=0.9) if not any(os.environ.get(k) for k in other) else (None, None)
     bank = sta.SawBank(n if inc is not None else 64)

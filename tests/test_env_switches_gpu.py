@@ -9,7 +9,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 SWITCHES = ["", "SMX_SAW_NO_WIDE", "SMX_SAW_NO_DEFER", "SMX_SAW_NO_SLOTS", "SMX_SAW_NO_CARRY", "SMX_SAW_NO_LONG_EVENTS", "SMX_NO_PUBLISH",
-            "SMX_POLY_NO_DEFER", "SMX_SAW_EVENTS_256", "SMX_PDM_NO_FEWTICKS", "SMX_BANK_TWO_ALLOCS", "SMX_SAW_NO_SHORT_EVENTS"]
+            "SMX_POLY_NO_DEFER", "SMX_SAW_EVENTS_256", "SMX_PDM_NO_FEWTICKS", "SMX_BANK_TWO_ALLOCS", "SMX_SAW_NO_SHORT_EVENTS",
+            "SMX_SAW_NO_EVENTS_128"]
 
 
 @pytest.mark.parametrize("switch", SWITCHES)
