@@ -472,7 +472,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
     SMX_FORM_AUTO, SMX_FORM_STEPPING = 0, 1
     if "saw_frames" in legs:
         # longer blocks of the same bank; 64 frames = the JACK operating point (linux/jack_midi.c:19-20)
-        for frames in (8, 16, 32, 64, 1024):
+        for frames in (8, 16, 32, 64, 128, 1024):
             # (blocks of 17..32 frames of >= 2^25-voice banks run as one 32-frame chunk of the same two forms;
             # with STEPPING pinned they keep the direct form: saw_bank.hip, launch_saw_bank)
             short = 16 < frames <= 32 and voices >= 1 << 25
@@ -497,7 +497,7 @@ def also_workloads(sta, synthetic, tab, big, voices, legs, verify):
                 if events:
                     # divisions, compares, selects, multiplies: mostly the 4.3-4.7-cycle class, some 2.7-cycle adds
                     with_recorded_issue(out[-1], ("saw_bank_event_long_kernel", "1024u") if frames >= 1024
-                                        else ("saw_bank_carry_kernel", "32, true" if short else "64, true"), 4.0)
+                                        else ("saw_bank_carry_kernel", "32, true" if short else "128, true" if frames > 64 else "64, true"), 4.0)
         big.bank.set_block_form(SMX_FORM_AUTO)
     if "saw_hi" in legs:
         # the same 64-frame blocks on a bank of high voices only (MIDI notes 100..127: 3..17 wraps per voice per
