@@ -14,3 +14,8 @@ for v in 16777216 67108864 268435456; do
   SYNTH_FILL=worst SYNTH_FORM_STEPPING=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync worst-case bank, SYNTH_FORM_STEPPING=1  /"
   SYNTH_FILL=1 SYNTH_FORM_STEPPING=1 SYNTH_FAKE_PERIOD_US=1333 SYNTH_VOICES=$v ./host/synth.dynamic.host.elf --fake-jack 300 64 /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync piano-range bank, SYNTH_FORM_STEPPING=1 /"
 done
+# other JACK block lengths of the 64 Mi-voice bank (round 3: one 32-frame chunk / one 128-frame chunk of the event form)
+for fr in 32 128 256; do
+  SYNTH_FILL=1 SYNTH_FAKE_PERIOD_US=$((fr * 1000000 / 48000)) SYNTH_VOICES=67108864 ./host/synth.dynamic.host.elf --fake-jack 300 $fr /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync, $fr-frame blocks          /"
+  SYNTH_FILL=1 SYNTH_FORM_STEPPING=1 SYNTH_FAKE_PERIOD_US=$((fr * 1000000 / 48000)) SYNTH_VOICES=67108864 ./host/synth.dynamic.host.elf --fake-jack 300 $fr /tmp/ev.bin /tmp/out.f32 < /dev/null 2>&1 | grep fake-jack | sed "s/^/sync, $fr-frame blocks, SYNTH_FORM_STEPPING=1 /"
+done
