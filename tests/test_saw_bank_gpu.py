@@ -472,8 +472,9 @@ def test_billion_voice_bank_index_safety(smx):
     """2^30 + 3072 voices (8 GiB of bank state; every byte offset beyond 2^32): the 1-frame tick
     path, a 16-frame block (direct formulation with bus slots) and a 64-frame block (carry
     formulation) against the closed form  bus[t] = sum_v ((int32)(state_v + t*inc_v) >> 4)
-    evaluated with numpy for frames 0, 1, 15 and 63, then the phases read back.  Voice values depend
-    on the index, so a workgroup reading the wrong rows (32-bit index wrap) changes the sums."""
+    evaluated with numpy for frames 0, 1, 15 and 63, then the phases read back; then the event forms of 32, 64 and 128
+    frames, pinned.  Voice values depend on the index, so a workgroup reading the wrong rows (32-bit index wrap) changes
+    the sums."""
     n = (1 << 30) + 3072
     idx = np.arange(n, dtype=np.uint64)
     inc = ((idx * np.uint64(2654435761)) >> np.uint64(7)).astype(np.uint32) | np.uint32(1)
@@ -505,6 +506,16 @@ def test_billion_voice_bank_index_safety(smx):
     assert np.array_equal(ginc, inc)
     want = state + np.uint32(64) * inc                    # inc == 0: unchanged
     assert np.array_equal(gst, want)
+    # the event forms pinned (arbitrary increments: ~32 wraps per voice and 64 frames, the loops run long): the 64-frame
+    # kernel in 512-thread workgroups, the 32-frame chunk, the 128-frame chunk in 1024-thread workgroups
+    bank.set_block_form(2)
+    f127 = closed_form(127)
+    for nf, checks in ((64, ((0, f0), (1, f1), (15, f15), (63, f63))), (32, ((0, f0), (1, f1), (15, f15))),
+                       (128, ((0, f0), (63, f63), (127, f127)))):
+        bank.load(inc, state)
+        bus, _ = bank.run(nf)
+        for t, f in checks:
+            assert bus[t] == wrap(f), ("events", nf, t)
     bank.close()
 
 
