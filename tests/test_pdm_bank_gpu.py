@@ -206,4 +206,15 @@ def test_quarter_billion_channels_index_safety(smx):
     gsp, gac = bank.read()
     assert np.array_equal(gsp, sp)
     assert np.array_equal(gac, a0 + np.uint32(T) * sp)
+    # the tick regime's read-stream kernel at this size (1 tick: per-word stores; 3 ticks: one 32-byte store per tick
+    # and wave-trip), from lazily kept accumulators: popcounts of the rows against the same floors
+    for nt in (1, 3):
+        rows = np.bitwise_count(bank.tick_n(nt)).sum(axis=1, dtype=np.int64)
+        acc = (a0.astype(np.uint64) + np.uint64(T) * sp) & np.uint64(0xFFFFFFFF)
+        for t in range(nt):
+            nxt = acc + sp
+            assert rows[t] == np.int64((nxt >> np.uint64(32)).sum(dtype=np.uint64)), (nt, t)
+            acc = nxt & np.uint64(0xFFFFFFFF)
+        T += nt
+    assert np.array_equal(bank.read()[1], a0 + np.uint32(T) * sp)
     bank.close()
