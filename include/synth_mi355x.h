@@ -122,7 +122,8 @@ int smx_bank_run(smx_bank *b, float *vec, int32_t *bus, int n);
 #define SMX_BLOCK_PIPELINED 1
 int smx_bank_set_block_mode(smx_bank *b, int mode);
 
-/* How blocks of more than 32 frames of a big launch (>= 2^16 voices, >= 2^30 voice-samples per launch)
+/* How long blocks of a big launch (more than 32 frames, >= 2^16 voices, >= 2^30 voice-samples per launch; see the end
+ * of this comment for 17..32 frames)
  * find the 32-bit wraps of the phases -- the only non-linear part of sum_tick_saw
  * (linux/synth.c:172-179); every form gives the same bits.  STEPPING adds inc frame by frame and
  * counts the carry-outs.  EVENTS locates each wrap directly (first at floor(~phase/inc), then every

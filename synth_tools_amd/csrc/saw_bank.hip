@@ -26,7 +26,7 @@
 //    event rebases one voice: state0 += T*(inc_old - inc_new) (saw_rebase_kernel), which
 //    keeps state0 + T*inc continuous -- the reference's "note_on does not reset the phase".
 //
-// Long blocks of big banks (> 32 frames, >= 2^30 voice-samples) take a second formulation
+// Long blocks of big banks (> 32 frames, >= 2^30 voice-samples; from 17 frames on >= 2^25 voices) take a second formulation
 // (saw_bank_carry_kernel) that needs 1.5 instead of 3 vector ops per voice-sample:
 // with u = state ^ 0x80000000 (offset binary) the arithmetic shift becomes a logical
 // one, (int)state >> 4 == (u >> 4) - 2^27, and because every term is a floor,
@@ -44,8 +44,9 @@
 //
 // W(t) is the ONLY per-sample non-linearity, and it can also be had without stepping: the wraps
 // of a voice lie at frame floor(~u/inc) and then every floor((2^32-1)/inc) or one more frames.
-// The EVENTS form of the carry kernel (64-frame chunks) and saw_bank_event_long_kernel (256-frame
-// chunks, launches of 256 frames and more) locate them and add them to a histogram -- work per
+// The EVENTS form of the carry kernel (one chunk of 32, 64 or 128 frames: blocks of 17..32, 33..64, 65..128 frames)
+// and saw_bank_event_long_kernel (256-frame chunks for launches of 129 frames and more, 1024-frame chunks from 1024)
+// locate them and add them to a histogram -- work per
 // WRAP instead of per sample, 1.1 wraps per voice per 64 frames on a piano-range bank.  Which
 // form runs is decided per launch ON THE DEVICE from the bank's own increment statistics (both
 // are queued, one returns at once); both are exact on any bank.
@@ -416,9 +417,10 @@ __device__ __forceinline__ uint32_t div_small(uint32_t a, uint32_t d, float rd)
 }
 
 // MULTI: more than one 64-frame chunk per launch (blockIdx.y).
-// TC: frames computed per chunk (64; blocks of up to 32 frames run the direct form, which is faster there since
-//   its accumulate became plain adds: 64 Mi voices x 32 frames 135 us against 138 us for a 32-frame stepping chunk).
-// EVENTS: the wraps are not found by stepping the phases but located directly (TC == 64 only):
+// TC: frames computed per chunk: 64; 32 for blocks of 17..32 frames of >= 2^25-voice banks (the stepping chunk equals
+//   the direct form there within 1-3 %: 64 Mi voices x 32 frames 139.6 against 138.5 us; what pays is the event form);
+//   128 (EVENTS only) for blocks of 65..128 frames.
+// EVENTS: the wraps are not found by stepping the phases but located directly:
 //   first wrap of a voice at frame  n1 = floor(~u / inc)            (u: offset-binary phase at chunk start)
 //   then gaps of                    Q + (r <= R),  Q = floor((2^32-1)/inc),  R = 2^32-1 - Q*inc
 //   residual                        r <- r + (r <= R ? E : E - inc),  E = inc-1-R,  r0 = u + (n1+1)*inc
@@ -637,8 +639,8 @@ void saw_bank_carry_kernel(const uint32_t *__restrict__ inc, const uint32_t *__r
     }
 }
 
-// The event form for launches of 256 frames and more: 256-frame chunks, so that the divisions are
-// paid once per 256 frames.  The wraps go to ONE histogram per workgroup (a per-lane matrix of 256
+// The event form for launches of 129 frames and more: 256-frame chunks, so that the divisions are
+// paid once per 256 frames (wraps are located only up to the frames the block needs: tlim).  The wraps go to ONE histogram per workgroup (a per-lane matrix of 256
 // frames would not fit), the nibble histogram travels to the slot as it is, and the finalize
 // kernel does the rest.  Slot layout of a 256-frame chunk:
 // (TL = 256; launches of 1024 frames and more use 1024-frame chunks, TL = 1024.)
