@@ -115,6 +115,40 @@ def test_bench_with_two_ranks_on_the_one_gpu(smx):
     assert line["collectives"]["block_sums_carried"] == 46 and line["collectives"]["issued"] <= 10
 
 
+def test_bench_under_the_drivers_torchrun_command(smx):
+    """The driver's own N > 1 launch -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks sharing the one GPU through the
+    RCCL test double: bench.py must take the ranks it is given (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+    agent), rendezvous among them, and rank 0 alone must print the one JSON line, with the bus check summed over both
+    ranks and the config-5 legs."""
+    fake = _fake_rccl()
+    if fake is None:
+        pytest.skip("hipcc not available to build the RCCL test double")
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:              # (not imported here: this process holds /opt/rocm's HIP runtime)
+        pytest.skip("torch (for its launcher) is not installed")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LD_PRELOAD=fake, SMX_BENCH_DEVICES="0,0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--voices", str(1 << 20), "--steps", "20", "--warmup", "5", "--repeats", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                              # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 20 and line["warmup"] == 5
+    assert "summed over 2 ranks" in line["verified"]
+    also = line["config"].get("also", line.get("also", []))
+    assert any("c5 as written" in e["workload"] for e in also)
+    assert all(e.get("verified") for e in also if "c5" in e["workload"])
+
+
 def test_bench_config5_legs_with_five_ranks_on_the_one_gpu(smx):
     """The line the one hardware shot at N > 1 will print, rehearsed with as many ranks as this box allows: the pool's
     process guard admits 6 processes on the card at once and this pytest process is one of them, so FIVE ranks share
