@@ -176,3 +176,56 @@ def test_input_staging_paths(smx, orc, n_inputs):
         assert np.array_equal(got, want), (n_inputs, nt)
     assert np.array_equal(bank.read_state(), state)
     bank.close()
+
+
+def test_dynamic_patcher_grows_between_ticks(smx, orc):
+    """Instances applied BETWEEN ticks (mod_bpmodular.c:84-113 after :72-78 has run): the network grows one node at a
+    time while it is running, earlier instances keep their state (the reference's bump allocator never moves them; here
+    the device state is re-reserved and copied when the node table grows), a new node starts from zero state, and state
+    poked from outside in between survives the next growth."""
+    from synth_tools_amd import PROC_ACC, PROC_EDGE, PROC_GPIN, PROC_GPOUT, cproc_input
+    n, n_inputs = 1300, 2
+    rng = np.random.default_rng(0x9A7C)
+    p = smx.Patch(n, n_inputs)
+    classes, kernel_nodes, kmap, gpouts = [], [], {}, []
+    state = np.zeros((0, 2, n), np.uint32)
+    for step in range(30):
+        if step < 2 or rng.random() < 0.2:
+            cls, src, cfg = PROC_GPIN, [], int(rng.integers(0, n_inputs))
+        else:
+            readable = [j for j, c in enumerate(classes) if c != PROC_GPOUT]
+            cls = int(rng.choice([PROC_ACC, PROC_EDGE, PROC_GPOUT]))
+            src, cfg = [int(rng.choice(readable))], 0
+        got = p.apply(cls, src, cfg)
+        assert got == len(classes), (step, got)
+        if cls == PROC_GPOUT:
+            kmap[got] = kmap[src[0]]
+            gpouts.append(got)
+        else:
+            kmap[got] = len(kernel_nodes)
+            kernel_nodes.append((cls, cproc_input(cfg) if cls == PROC_GPIN else kmap[src[0]], 0xFFFFFFFF))
+            state = np.concatenate([state, np.zeros((1, 2, n), np.uint32)])      # a new instance starts from zero (cproc.h:65-66)
+        classes.append(cls)
+        if step % 5 == 3:                                    # poke an earlier instance between growths
+            node = int(rng.choice([j for j, c in enumerate(classes) if c in (PROC_ACC, PROC_EDGE)] or [0]))
+            if classes[node] in (PROC_ACC, PROC_EDGE):
+                vals = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+                assert p.state_set(node, 0, vals) == 0
+                state[kmap[node], 0] = vals
+        nt = int(rng.integers(1, 9))
+        inp = rng.integers(0, 3, (nt, n_inputs, n)).astype(np.uint32)
+        if gpouts:                                           # the last sink's words of these ticks
+            gp = gpouts[-1]
+            res = p.tick(nt, inp, gp)
+            want = _oracle_run(orc, kernel_nodes, n, n_inputs, state, inp, None, kmap[gp])
+            assert np.array_equal(res, want), step
+        else:                                                # no sink yet: the ticks run all the same
+            p.tick(nt, inp)
+            _oracle_run(orc, kernel_nodes, n, n_inputs, state, inp, None, kmap[got])
+    for node, cls in enumerate(classes):
+        if cls == PROC_GPOUT:
+            continue
+        assert np.array_equal(p.state_get(node, 0), state[kmap[node], 0]), node
+        if cls == PROC_EDGE:
+            assert np.array_equal(p.state_get(node, 1), state[kmap[node], 1]), node
+    p.close()
