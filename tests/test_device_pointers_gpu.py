@@ -171,3 +171,64 @@ def test_osc_load_pmeas_resumes_a_measurement(smx, orc):
     assert int(want["write"].max()) >= 2
     a.close()
     b.close()
+
+
+def test_create_destroy_leaves_no_device_memory_behind(smx, inc_table):
+    """Every bank kind created, used (so that its lazily allocated buffers exist: bus ring, scratch, staging, pulse and
+    duty matrices, pinned words) and destroyed, fifty times over: hipMemGetInfo's free figure is back where it
+    started (within the allocator's granularity)."""
+    h = C.CDLL("libamdhip64.so")
+    h.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert h.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    from synth_tools_amd import PROC_ACC, PROC_EDGE, PROC_GPIN, cproc_input
+    n = (1 << 20) + 4096
+
+    def cycle():
+        inc, st = synthetic.saw_bank(n, 0x5EED0D00, inc_table)
+        b = smx.SawBank(n)
+        b.load(inc, st)
+        b.run(64); b.run_async(300); b.run_async(5000); b.fetch(64)
+        b.midi_events(np.array([[0x90, 60, 64], [0x80, 60, 0]], np.uint8))
+        b.set_block_mode(True); b.run(64); b.run(64)
+        b.close()
+        p = smx.PdmBank(n)
+        p.init(); p.tick_n(70); p.tick_n(2); p.tick_n_streams(64)
+        p.close()
+        w = smx.PwmBank(1 << 16)
+        w.init(); w.tick_n(40, synthetic.dither_stream(40, 1, 0x3FF))
+        w.close()
+        o = smx.OscBank(5000)
+        o.tick_n(33); o.events(np.zeros((2, 5000), np.uint32))
+        o.close()
+        y = smx.PolyBank(1 << 16)
+        y.run(64); y.run_async(7)
+        y.close()
+        c = smx.CprocBank(3000, [(PROC_EDGE, cproc_input(0), 1), (PROC_ACC, 0, 1)], 1)
+        c.tick_n(np.zeros((8, 1, 3000), np.uint32))
+        c.close()
+        t = smx.Patch(3000, 1)
+        t.apply(PROC_GPIN, [], 0); t.apply(PROC_ACC, [0]); t.tick(3, np.zeros((3, 1, 3000), np.uint32))
+        t.close()
+        m = smx.ModPdm(70, 3)
+        m.tick_n(300)
+        m.close()
+        f = smx.Firmware()
+        f.tick_n(10)
+        f.close()
+        k = smx.ClockBank(100)
+        k.run(64)
+        k.close()
+
+    cycle()                                                  # the runtime's own pools settle
+    cycle()
+    before = free_bytes()
+    for _ in range(50):
+        cycle()
+    after = free_bytes()
+    print("free device memory: %d KiB less after 50 cycles" % ((before - after) >> 10))
+    assert before - after < (8 << 20), "device memory shrank by %d KiB over 50 create/destroy cycles" % ((before - after) >> 10)
