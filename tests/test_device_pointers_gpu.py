@@ -224,11 +224,20 @@ def test_create_destroy_leaves_no_device_memory_behind(smx, inc_table):
         k.run(64)
         k.close()
 
+    def host_side():
+        rss_pages = int(open("/proc/self/statm").read().split()[1])
+        return rss_pages * os.sysconf("SC_PAGE_SIZE"), len(os.listdir("/proc/self/fd"))
+
     cycle()                                                  # the runtime's own pools settle
     cycle()
     before = free_bytes()
+    rss0, fds0 = host_side()
     for _ in range(50):
         cycle()
     after = free_bytes()
+    rss1, fds1 = host_side()
+    print("host side: rss %+d MiB, open descriptors %+d after 50 cycles" % ((rss1 - rss0) >> 20, fds1 - fds0))
+    assert fds1 - fds0 <= 2, "descriptors leak: %d -> %d" % (fds0, fds1)            # streams / events / pinned mappings
+    assert rss1 - rss0 < (256 << 20), "resident set grew by %d MiB" % ((rss1 - rss0) >> 20)   # pinned buffers are resident
     print("free device memory: %d KiB less after 50 cycles" % ((before - after) >> 10))
     assert before - after < (8 << 20), "device memory shrank by %d KiB over 50 create/destroy cycles" % ((before - after) >> 10)
