@@ -158,3 +158,41 @@ def test_every_call_in_random_order(smx, orc, inc_table, n):
         ginc, gst = bank.read()
         assert np.array_equal(ginc, m.inc) and np.array_equal(gst, m.st), " | ".join(log[-12:])
         bank.close()
+
+
+def test_banks_on_concurrent_host_threads(smx, orc, inc_table):
+    """One bank per host thread, four threads at once (ctypes releases the GIL inside every call): each bank has its own
+    stream, pinned words and error string; nothing in the library is shared between banks except lazily initialised
+    read-only switches.  Every thread checks its blocks against the oracle (a second oracle call runs under the GIL:
+    the product calls are what overlap)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def worker(k):
+        n = [64, 5000, 70000, (1 << 20) + 4096][k]
+        rng = np.random.default_rng(0x7123 + k)
+        inc, st = synthetic.saw_bank(n, 0x5EED0710 + k, inc_table, active_fraction=0.8)
+        bank = smx.SawBank(n)
+        bank.load(inc, st)
+        st = st.copy()
+        pdm = smx.PdmBank(3000 + k)
+        sp, ac = synthetic.pdm_bank(3000 + k, 0x710 + k)
+        pdm.load(sp, ac)
+        oa = ac.copy()
+        for step in range(25):
+            nf = int(rng.choice([1, 16, 33, 64, 64, 128]))
+            if step % 4 == 3:
+                bank.run_async(nf)
+                bus = bank.fetch(nf)[0]
+            else:
+                bus = bank.run(nf)[0]
+            want, _ = oracle.synth_run(orc, inc, st, nf)
+            assert np.array_equal(bus, want), (k, step, nf)
+            nt = int(rng.choice([1, 2, 40]))
+            assert np.array_equal(pdm.tick_n(nt), oracle.pdm_run(orc, sp, oa, nt)), (k, step, "pdm")
+        assert np.array_equal(bank.read()[1], st)
+        bank.close()
+        pdm.close()
+        return k
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        assert sorted(ex.map(worker, range(4))) == [0, 1, 2, 3]
