@@ -28,10 +28,20 @@ def main():
         bank.set_block_form(form)
         for k, nf in enumerate(frames):
             bank.run_async(nf)
-            want, _ = oracle.synth_run(orc, inc, st, nf, want_vec=False)
+            if n >= (1 << 23):
+                # 2^23 voices: three frames of the bus against the closed form of the linear phasor (stepping them on
+                # the CPU in fourteen processes is most of this test's time); the final phases are compared below
+                pick = sorted({0, nf // 2, nf - 1})
+                with np.errstate(over="ignore"):
+                    w = [int(np.where(inc != 0, (st + np.uint32(f) * inc).view(np.int32) >> 4, 0).sum(dtype=np.int64)) for f in pick]
+                    st += np.uint32(nf) * inc
+                want = ((np.array(w, np.int64) + (1 << 31)) % (1 << 32) - (1 << 31)).astype(np.int32)
+            else:
+                pick = slice(None)
+                want, _ = oracle.synth_run(orc, inc, st, nf, want_vec=False)
             if k % 2 == 1 or k == len(frames) - 1:          # un-fetched blocks in between
                 bus, _ = bank.fetch(nf)
-                assert np.array_equal(bus, want), (n, nf, form)
+                assert np.array_equal(bus[pick], want), (n, nf, form)
                 checks += 1
         assert np.array_equal(bank.read()[1], st), (n, "phases")
         bank.close()
