@@ -64,11 +64,23 @@ void orc_note_off(int *note2voice, uint32_t *inc, uint32_t n, int note) {
 }
 
 /* linux/synth.c:169-179: integer part of sum_tick_saw.  State is read
- * BEFORE the increment; voices with inc==0 neither contribute nor advance.
- * The reference's `if (inc) { sum += p >> 4; state += inc; }` is written without the branch -- the term is masked
- * and adding an increment of 0 is no advance -- because on a half-active bank of 2^25 voices the branch is a coin
- * toss per voice (33 s instead of 4 s per test); the compiled reference pins this function in the CPU tests. */
+ * BEFORE the increment; voices with inc==0 neither contribute nor advance. */
 int32_t orc_sum_tick_saw(const uint32_t *inc, uint32_t *state, uint32_t n) {
+    int32_t sum = 0;
+    for (uint32_t v = 0; v < n; v++) {
+        if (inc[v]) {
+            int32_t p = (int32_t)state[v];
+            sum += (p >> 4);
+            state[v] += inc[v];
+        }
+    }
+    return sum;
+}
+/* The same tick without the branch (the term is masked; adding an increment of 0 is no advance): what orc_synth_run
+ * uses on the tests' big banks, where `if (inc)` on a half-active bank is a coin toss per voice (a 2^25-voice test:
+ * 33 s with the branch, 7 s without).  tests/test_oracle_golden.py holds it against orc_sum_tick_saw; the timed CPU
+ * baselines of bench.py (banks of up to 2^20 voices) keep the reference's loop as it is. */
+static int32_t sum_tick_saw_branch_free(const uint32_t *inc, uint32_t *state, uint32_t n) {
     int32_t sum = 0;
     for (uint32_t v = 0; v < n; v++) {
         const uint32_t i = inc[v];
@@ -88,10 +100,11 @@ float orc_bus_to_float(int32_t sum) {
 /* linux/synth.c:182-195 (unused by synth_run; OR of the sign bits). */
 float orc_sum_tick_square(const uint32_t *inc, uint32_t *state, uint32_t n) {
     uint32_t accu = 0;
-    for (uint32_t v = 0; v < n; v++) {                  /* branch-free like orc_sum_tick_saw */
-        const uint32_t i = inc[v];
-        accu |= state[v] & 0x80000000u & (0u - (uint32_t)(i != 0));
-        state[v] += i;
+    for (uint32_t v = 0; v < n; v++) {
+        if (inc[v]) {
+            accu |= state[v] & 0x80000000u;
+            state[v] += inc[v];
+        }
     }
     return (float)((1.0 / 4294967296.0) * (double)((float)accu));
 }
@@ -100,7 +113,7 @@ float orc_sum_tick_square(const uint32_t *inc, uint32_t *state, uint32_t n) {
 void orc_synth_run(const uint32_t *inc, uint32_t *state, uint32_t n,
                    float *vec, int32_t *bus, int nframes) {
     for (int i = 0; i < nframes; i++) {
-        int32_t s = orc_sum_tick_saw(inc, state, n);
+        int32_t s = n > (1u << 20) ? sum_tick_saw_branch_free(inc, state, n) : orc_sum_tick_saw(inc, state, n);
         if (bus) bus[i] = s;
         if (vec) vec[i] = orc_bus_to_float(s);
     }

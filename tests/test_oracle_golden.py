@@ -80,6 +80,25 @@ def test_inactive_voices_do_not_advance(orc):
     assert bus.tolist() == [(22 >> 4) + (44 >> 4), (27 >> 4) + (51 >> 4), (32 >> 4) + (58 >> 4)]
 
 
+def test_big_bank_tick_without_the_branch_is_the_same_tick(orc):
+    """orc_synth_run steps banks above 2^20 voices with a branch-free statement of sum_tick_saw (linux/synth.c:169-179;
+    a half-active bank makes `if (inc)` a coin toss per voice): same bus, same phases as the reference's loop taken
+    tick by tick with orc_sum_tick_saw, on a half-active bank with arbitrary increments."""
+    import numpy as np
+    import oracle
+    n = (1 << 20) + 77
+    rng = np.random.default_rng(0x0B1A5)
+    inc = rng.integers(1, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    inc[rng.random(n) < 0.5] = 0
+    st0 = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    a = st0.copy()
+    bus, _ = oracle.synth_run(orc, inc, a, 9)
+    b = st0.copy()
+    want = np.array([orc.orc_sum_tick_saw(inc, b, n) for _ in range(9)], np.int32)
+    assert np.array_equal(bus, want) and np.array_equal(a, b)
+    assert np.array_equal(a[inc == 0], st0[inc == 0])            # off voices do not advance
+
+
 def test_bus_to_float_is_exact_power_of_two_scale(orc):
     for s in (0, 1, -1, 2**31 - 1, -2**31, 123456789, -987654321, 0x01000001):
         want = np.float32(np.float32(s) * np.float32(2.0 ** -32))
