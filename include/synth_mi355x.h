@@ -91,7 +91,9 @@ uint32_t  smx_bank_voices(const smx_bank *b);
 int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *state);
 int smx_bank_read(smx_bank *b, uint32_t *inc, uint32_t *state);
 /* smx_bank_load(inc, state) + smx_bank_run(vec, bus, n) with a single host
- * synchronisation (what the drop-in synth_run does per block). */
+ * synchronisation (what the drop-in synth_run does for blocks longer than 1024 frames; shorter ones are one
+ * launch with the voices as kernel arguments).  Both arrays are required; the caller's arrays may change as soon as
+ * the call returns.  Not for a sharded bank (SMX_E_STATE: its loads are collective, smx_bank_load). */
 int smx_bank_load_run(smx_bank *b, const uint32_t *inc, const uint32_t *state, float *vec,
                       int32_t *bus, int n);
 
