@@ -168,6 +168,58 @@ def main():
             want = expect(64)[0]
         assert np.array_equal(bank.fetch(64)[0], want), ("async after sync", rnd)
         res["checks"] += 2
+    # (7) a seeded random sequence, the SAME on every rank (the SPMD contract): synchronous blocks, requested sums
+    # left queued, blocks WITHOUT a request in between (a gap closes the group), fetched and un-fetched, groups of
+    # 1..16, the pipelined mode on and off, the square variant, syncs, and long blocks that re-stride the bus ring
+    # (after which a group of short blocks is "mostly gap" and goes as one grouped launch of per-block sums)
+    rng = np.random.default_rng(int(os.environ.get("SMX_FUZZ_SEED", "0x5EED7"), 0))
+    pipelined, prev = False, None
+    for step in range(int(os.environ.get("SMX_TEST_RANDOM_STEPS", "70"))):
+        r = rng.random()
+        nf = int(rng.choice([1, 1, 7, 16, 64, 64, 64, 65, 300, 2000]))
+        tag = ("random", step, nf)
+        if pipelined:
+            if r < 0.8:
+                bus, _ = bank.run(nf)
+                want = np.zeros(nf, np.int32)
+                if prev is not None:
+                    m = min(nf, len(prev))
+                    want[:m] = prev[:m]
+                assert np.array_equal(bus, want), tag + ("pipelined",)
+                prev = expect(nf)[0]
+                res["checks"] += 1
+            else:
+                bank.set_block_mode(0); bank.sync(); pipelined = False
+        elif r < 0.30:
+            bus, _ = bank.run(nf)
+            assert np.array_equal(bus, expect(nf)[0]), tag + ("sync",)
+            res["checks"] += 1
+        elif r < 0.65:
+            bank.run_async(nf)
+            bank.allreduce_async(nf)
+            want = expect(nf)[0]
+            if rng.random() < 0.4:
+                assert np.array_equal(bank.fetch(nf)[0], want), tag + ("async+fetch",)
+                res["checks"] += 1
+        elif r < 0.73:
+            bank.run_async(nf)                          # no sum requested: its bus stays this rank's own
+            expect(nf)
+        elif r < 0.80:
+            bank.set_comm_group(int(rng.integers(1, 17)))
+        elif r < 0.85:
+            bank.sync()
+        elif r < 0.90:
+            k = int(rng.integers(1, 4))
+            got = bank.run_square(k)
+            want = np.array([orc.orc_sum_tick_square(all_inc, all_st, len(all_inc)) for _ in range(k)], np.float32)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), tag + ("square",)
+            res["checks"] += 1
+        else:
+            bank.sync(); bank.set_block_mode(1); pipelined, prev = True, None
+    if pipelined:
+        bank.set_block_mode(0)
+    bank.sync()
+    bank.set_comm_group(8)
     # phases of the shard after everything
     _, st = bank.read()
     assert np.array_equal(st, all_st[rank * per:(rank + 1) * per])

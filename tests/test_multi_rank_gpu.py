@@ -35,7 +35,9 @@ def _run(world, devices, voices=5000, timeout=240, preload=None, extra_env=None)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), SMX_RDZV_DIR=rdzv,
-                   SMX_TEST_DEVICE=str(devices[r]), SMX_TEST_VOICES=str(voices), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   SMX_TEST_DEVICE=str(devices[r]), SMX_TEST_VOICES=str(voices), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   # the worker's random section steps ALL shards on the CPU: fewer steps on the big banks
+                   SMX_TEST_RANDOM_STEPS="20" if voices * world >= (1 << 20) else "70")
         if preload:
             env["LD_PRELOAD"] = preload
         env.update(extra_env or {})
