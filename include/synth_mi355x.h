@@ -137,7 +137,8 @@ int smx_bank_set_block_mode(smx_bank *b, int mode);
  * running sum above the bound selects stepping at once), so the event form never runs on a bank outside
  * the rule: on every bank the rule admits it was measured at most as slow as stepping -- a
  * real-time caller (the JACK process callback, linux/synth.c:277-282) gets at most the stepping form's time.
- * The first long block after smx_bank_load(inc) steps.  STEPPING / EVENTS pin a form.
+ * smx_bank_load(inc) applies the rule to the loaded increments (exact sum and maximum), so the first long block after
+ * a load already runs the right form.  STEPPING / EVENTS pin a form.
  * Blocks of 17..32 frames of banks of 2^25 voices and more take the same two forms as one 32-frame chunk under AUTO
  * and EVENTS (a piano-range bank: 61 instead of 48 % of the HBM peak on 64 Mi voices); with STEPPING pinned they run
  * the direct form, like every shorter block. */

@@ -272,7 +272,7 @@ static int bank_ensure_bus(smx_bank *b, uint32_t n)
         static const bool no_defer = getenv("SMX_SAW_NO_DEFER") != nullptr;      // A/B switch: every launch folds its own slots
         b->pend = smx::SawPending{};
         b->pend.region_stride = no_defer ? 0 : smx::saw_scratch_region_bytes(scap);
-        // a new header: the form pick starts at "stepping", the sum of the increments is computed again
+        // a new header: the sum of the increments and the form pick are computed again
         int rv = smx::launch_saw_sum_inc(b->d_inc, b->n_pad, b->d_scratch, b->stream);
         if (rv) return rv;
         bank_form_unpin(b);
@@ -467,8 +467,8 @@ extern "C" int smx_bank_load(smx_bank *b, const uint32_t *inc, const uint32_t *s
         } else {
             b->free_map.load(inc, b->n);
         }
-        // new increments: the statistic that picks the long-block form is void (stepping until the
-        // next long block has measured the new bank)
+        // new increments: the statistic that picks the long-block form is computed again from them (sum and maximum
+        // of the whole bank: launch_saw_sum_inc), what the host has seen of the old bank's picks is void
         if (b->d_scratch) {
             SMX_HIP(hipMemsetAsync(b->d_scratch, 0, smx::saw_scratch_header_bytes(), b->stream));
             rv = smx::launch_saw_sum_inc(b->d_inc, b->n_pad, b->d_scratch, b->stream);    // the header's sum of increments

@@ -105,6 +105,7 @@ struct SawPartial {
 //       their start -- the one that is not selected returns at once;
 //   [1] which slot layout the launch filled (for the finalize kernel);
 //   [2] number of long blocks finalized so far (copied to the host's mirror: tells a fresh pick from an old one);
+//   [3] largest increment as of the last load (saw_sum_inc_kernel; only read by saw_stats_init_kernel);
 //   [4..5] exact sum of all increments: computed when the increments are loaded (saw_sum_inc_kernel), kept
 //          current by the note-event kernels; the finalize kernels take the bank's I from here (the main kernels
 //          do not add the increments up again at every launch).
@@ -1053,18 +1054,36 @@ void saw_rebase_batch_kernel(uint32_t *__restrict__ inc, uint32_t *__restrict__ 
     inc[voice] = new_inc;
     if (hdr) saw_stats_note(hdr, nvoices, old, new_inc);
 }
-// I = sum of all increments, into the scratch header (after the increments were loaded; the header was cleared).
+// I = sum of all increments, into the scratch header (after the increments were loaded; the header was cleared),
+// and their maximum into word [3]: saw_stats_init_kernel, queued behind this one, turns both into the form pick of
+// the bank's first long block (round 3: the pick used to start at "stepping" and only a long block's finalize set it).
 __global__ __launch_bounds__(256)
 void saw_sum_inc_kernel(const uint32_t *__restrict__ inc, uint32_t n_pad, uint32_t *__restrict__ hdr)
 {
     unsigned long long s = 0;
+    uint32_t mx = 0;
     const u32x4 *inc4 = reinterpret_cast<const u32x4 *>(inc);          // n_pad is a multiple of 1024
     for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < n_pad / 4; g += gridDim.x * 256u) {
         const u32x4 a = inc4[g];
         s += (unsigned long long)a.x + a.y + a.z + a.w;
+        mx = max(max(mx, a.x), max(max(a.y, a.z), a.w));
     }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(hdr + 4), s);
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (s) atomicAdd(reinterpret_cast<unsigned long long *>(hdr + 4), s);
+        if (mx) atomicMax(hdr + 3, mx);
+    }
+}
+// The rule of saw_bank_finalize_kernel on the loaded increments (exact: sum and maximum of the whole bank).
+__global__ void saw_stats_init_kernel(uint32_t *__restrict__ hdr, uint32_t nvoices)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned long long I = saw_stats_sum_inc(hdr);
+        hdr[0] = (hdr[3] < SAW_EVENTS_MAX_INC && I <= ((unsigned long long)nvoices << 27)) ? 1u : 0u;
+    }
 }
 // Materialise every phase: state0 += T*inc (the host then resets T to 0).
 __global__ __launch_bounds__(256)
@@ -1499,6 +1518,7 @@ int launch_saw_sum_inc(const uint32_t *d_inc, uint32_t n_pad, void *d_scratch, h
     uint32_t gx = n_pad / 1024;
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(saw_sum_inc_kernel, dim3(gx), dim3(256), 0, stream, d_inc, n_pad, static_cast<uint32_t *>(d_scratch));
+    hipLaunchKernelGGL(saw_stats_init_kernel, dim3(1), dim3(64), 0, stream, static_cast<uint32_t *>(d_scratch), n_pad);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

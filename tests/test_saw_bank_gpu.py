@@ -224,7 +224,7 @@ _FORMS_ORACLE, _FORMS_ORACLE_SEQ = {}, {}
 @pytest.mark.parametrize("form", [1, 2, 0])       # SMX_FORM_STEPPING, SMX_FORM_EVENTS, SMX_FORM_AUTO
 def test_long_block_forms_agree(smx, orc, inc_table, form):
     """smx_bank_set_block_form: stepping, wrap events and the device-side automatic choice give the
-    oracle's bits on a piano-range bank (where AUTO switches to events after its first long block),
+    oracle's bits on a piano-range bank (where AUTO runs the event form from its first long block on),
     on arbitrary 32-bit increments (many wraps per voice: the event loop runs long, the result must
     not care), on all-wrap / never-wrap / half-scale increments, with voices off, over single
     chunks, partial chunks and multi-chunk launches, and across a reload of the increments.
@@ -258,7 +258,7 @@ def test_long_block_forms_agree(smx, orc, inc_table, form):
         blocks(piano_blocks)
         assert np.array_equal(bank.read()[1], st)
         inc = _adversarial_increments(n)
-        bank.load(inc=inc)                                 # resets the statistic: stepping first under AUTO
+        bank.load(inc=inc)                                 # the statistic is computed again: outside the rule, AUTO steps
         blocks(hard_blocks)
         inc = synthetic.saw_bank(n, 0x5EED0E0F, inc_table, active_fraction=1.0)[0]
         bank.load(inc=inc)
@@ -559,9 +559,9 @@ def test_auto_form_statistic_is_conservative_under_note_events(smx, orc, inc_tab
         obus, _ = oracle.synth_run(orc, inc, st, 64, want_vec=False)
         assert np.array_equal(bus, obus)
 
-    assert bank.next_block_form() == FORM_STEPPING                      # after a load: unknown -> stepping
+    assert bank.next_block_form() == FORM_EVENTS                        # after a load: the rule on the loaded increments (round 3)
     block()
-    assert bank.next_block_form() == FORM_EVENTS                        # measured by that block: inside the rule
+    assert bank.next_block_form() == FORM_EVENTS                        # measured again by that block: inside the rule
     block()
     # one very high voice (MIDI 127: 16.7 wraps per 64 frames): stepping at once
     n2v = np.zeros(128, np.int32)
@@ -581,8 +581,14 @@ def test_auto_form_statistic_is_conservative_under_note_events(smx, orc, inc_tab
     inc2[:4096] = 0
     inc[:] = inc2
     bank.load(inc=inc2)
+    assert bank.next_block_form() == FORM_EVENTS                        # mean just below 2 wraps: known from the load on
     block()
-    assert bank.next_block_form() == FORM_EVENTS                        # mean just below 2 wraps
+    assert bank.next_block_form() == FORM_EVENTS
+    hi = inc2.copy()
+    hi[5000] = 15 << 25                                                 # one voice above the per-voice bound
+    bank.load(inc=hi)
+    assert bank.next_block_form() == FORM_STEPPING                      # ... and so is this
+    bank.load(inc=inc2)
     ev = np.array([[0x90, 100 + (k % 8), 100] for k in range(3000)], np.uint8)   # notes 100..107: 3.6 .. 5.3 wraps each
     bank.midi_events(ev)
     for m in ev:
